@@ -1,0 +1,312 @@
+"""Generates the golden fixtures in tests/golden/*.npz by RUNNING THE REFERENCE'S OWN MODULES.
+
+Runs only in the build container (needs /root/reference).  The reference has no tests or golden
+vectors of its own, so every fixture here is an output of the reference code on
+seeded inputs; inputs are reproducible on any machine from the portable RNG (oracle/rng.py), so only
+outputs (and tiny inputs) are stored.  Fixtures are data: no reference source text is stored.
+
+    python tests/golden/make_golden.py            # all
+    python tests/golden/make_golden.py rng unet   # subsets
+
+Shim: `diffusers` / `numba` are not installed; they are replaced by ~30 lines of serialisation-only
+stand-ins so the reference's arithmetic modules import unchanged.
+"""
+import ast
+import functools
+import inspect
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+
+# ----------------------------------------------------------------------------- reference import shim
+def install_shim():
+    class _Cfg(dict):
+        __getattr__ = dict.get
+
+    class ConfigMixin:
+        def register_to_config(self, **kw):
+            self.__dict__.setdefault("_cfg", _Cfg()).update(kw)
+        config = property(lambda self: self._cfg)
+
+    def register_to_config(init):
+        @functools.wraps(init)
+        def wrap(self, *a, **kw):
+            ba = inspect.signature(init).bind(self, *a, **kw)
+            ba.apply_defaults()
+            ConfigMixin.register_to_config(self, **{k: v for k, v in ba.arguments.items() if k != "self"})
+            init(self, *a, **kw)
+        return wrap
+
+    class ModelMixin(torch.nn.Module):
+        pass
+
+    class SchedulerMixin:
+        pass
+
+    class SchedulerOutput:
+        def __init__(self, prev_sample):
+            self.prev_sample = prev_sample
+
+    def _mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+
+    _mod("diffusers", ConfigMixin=ConfigMixin)
+    _mod("diffusers.configuration_utils", ConfigMixin=ConfigMixin, register_to_config=register_to_config)
+    _mod("diffusers.models")
+    _mod("diffusers.models.modeling_utils", ModelMixin=ModelMixin)
+    _mod("diffusers.utils")
+    _mod("diffusers.utils.torch_utils",
+         randn_tensor=lambda shape, generator=None, device=None, dtype=None: torch.randn(shape, generator=generator, device=device, dtype=dtype))
+    _mod("diffusers.schedulers")
+    _mod("diffusers.schedulers.scheduling_utils", SchedulerMixin=SchedulerMixin, SchedulerOutput=SchedulerOutput)
+    _mod("numba", njit=lambda *a, **k: a[0] if a and callable(a[0]) else (lambda f: f))
+    sys.path.insert(0, REF)
+
+
+def extract_functions(path, names, namespace):
+    """exec only the named pure FunctionDefs of a reference file whose module import needs absent deps."""
+    tree = ast.parse(open(path).read())
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    mod = ast.Module(body=body, type_ignores=[])
+    exec(compile(mod, path, "exec"), namespace)
+    return namespace
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ----------------------------------------------------------------------------- fixtures
+def gen_rng():
+    from terrain_diffusion.inference import portable_rng as pr
+    ns = extract_functions(os.path.join(REF, "terrain_diffusion/inference/world_pipeline.py"),
+                           {"_tile_seed", "gaussian_noise_patch"},
+                           {"np": np, "torch": torch, "fill_standard_normal": pr.fill_standard_normal})
+    out = {}
+    seeds = [1, 42, 123, 0xFFFFFFFFFFFFFFFF, 785323394005271306]
+    out["stream_seeds"] = np.array(seeds, dtype=np.uint64)
+    streams = []
+    for s in seeds:
+        st, o = s, []
+        for _ in range(64):
+            st, u = pr._pcg64_next(st)
+            o.append(u)
+        streams.append(o)
+    out["streams"] = np.array(streams, dtype=np.uint32)
+    out["next_seed_in"] = np.array([1, 42, 2 ** 63 + 5], dtype=np.uint64)
+    out["next_seed_out"] = np.array([pr.next_seed(int(s)) for s in out["next_seed_in"]], dtype=np.uint64)
+    out["normal_seed123_n4097"] = pr.standard_normal(123, (4097,))
+    out["normal_seed7_f64_n33"] = pr.standard_normal(7, (33,), dtype=np.float64)
+    ts = [(42, 0, 0), (42, -1, 3), (42, 5, -7), (0xFFFFFFFFFFFFFFFF, -2 ** 31, 2 ** 31 - 1), (1234567890123, 100000, -100000),
+          (42 + 5819, 17, 17), (2 ** 64 + 5, 1, 1), (-3, 2, 2)]
+    out["tile_seed_in"] = np.array([[a & 0xFFFFFFFFFFFFFFFF, b & 0xFFFFFFFFFFFFFFFF, c & 0xFFFFFFFFFFFFFFFF] for a, b, c in ts], dtype=np.uint64)
+    out["tile_seed_in_signed"] = np.array([[b, c] for _, b, c in ts], dtype=np.int64)
+    out["tile_seed_out"] = np.array([ns["_tile_seed"](*t) for t in ts], dtype=np.uint64)
+    gnp = ns["gaussian_noise_patch"]
+    # latent-stage call shape (world_pipeline.py:1090-1093): window straddling 4 noise tiles, negative coords
+    out["patch_latent_m32_32"] = gnp(42, -32, 32, 64, 64, channels=5, tile_h=64, tile_w=64)
+    out["patch_latent_aligned"] = gnp(42 + 5819, 128, -64, 64, 64, channels=5, tile_h=64, tile_w=64)
+    # coarse-stage call shape (world_pipeline.py:928-938): multiples of 48 on a 64-tile grid, 6 channels
+    out["patch_coarse_48_m96"] = gnp(43, 48, -96, 64, 64, channels=6, tile_h=64, tile_w=64)
+    # ragged / small windows and non-square tiles
+    out["patch_small"] = gnp(7, -3, 61, 7, 9, channels=2, tile_h=16, tile_w=32)
+    out["patch_1x1"] = gnp(7, -1, -1, 1, 1, channels=1, tile_h=8, tile_w=8)
+    # decoder-stage call shape (world_pipeline.py:1229-1232): (1,512,512) on a 512 grid at multiples of 384 — store a strided sample
+    dec = gnp(42 + 5819, 384, -384, 512, 512, channels=1, tile_h=512, tile_w=512)
+    out["patch_decoder_stride37"] = dec.ravel()[::37].copy()
+    out["patch_decoder_sum"] = np.array([dec.astype(np.float64).sum(), np.abs(dec.astype(np.float64)).sum()])
+    save("rng", **out)
+
+
+def gen_geometry():
+    from terrain_diffusion.training.evaluation import _linear_weight_window, _tile_starts
+    pano = extract_functions(os.path.join(REF, "annotated_infinite_panorama.py"), {"linear_kernel", "build_timestep_ranges"},
+                             {"np": np, "torch": torch})
+    wp = extract_functions(os.path.join(REF, "terrain_diffusion/inference/world_pipeline.py"), {"linear_weight_window", "normalize_tensor"},
+                           {"np": np, "torch": torch})
+    out = {}
+    for s in (4, 16, 64, 512):
+        out[f"lww_{s}"] = _linear_weight_window(s, torch.device("cpu"), torch.float32)[0, 0].numpy()
+        assert torch.equal(wp["linear_weight_window"](s, torch.device("cpu"), torch.float32), torch.from_numpy(out[f"lww_{s}"]))
+    out["pano_kernel_64"] = pano["linear_kernel"](64, 64).numpy()
+    out["pano_kernel_8x512"] = pano["linear_kernel"](8, 512).numpy()
+    cases = [(64, 64, 32), (288, 64, 32), (1056, 64, 32), (100, 64, 32), (65, 64, 32), (10, 64, 32), (96, 64, 32), (130, 64, 48), (512, 512, 384), (33, 16, 8)]
+    out["tile_starts_cases"] = np.array(cases, dtype=np.int64)
+    starts = [_tile_starts(*c) for c in cases]
+    out["tile_starts_len"] = np.array([len(s) for s in starts], dtype=np.int64)
+    out["tile_starts_flat"] = np.array([v for s in starts for v in s], dtype=np.int64)
+    # DDIM-style descending timesteps (50 of 1000, leading spacing as diffusers: 981, 961, ..., 1)
+    ts = torch.arange(49, -1, -1) * 20 + 1
+    ranges = pano["build_timestep_ranges"](ts, (400, 600, 750, 900))
+    out["ddim_timesteps"] = ts.numpy()
+    out["phase_len"] = np.array([len(r) for r in ranges], dtype=np.int64)
+    out["phase_flat"] = torch.cat(ranges).numpy()
+    ts4 = torch.tensor([751, 501, 251, 1])
+    r4 = pano["build_timestep_ranges"](ts4, (400, 600, 750, 900))
+    out["phase4_len"] = np.array([len(r) for r in r4], dtype=np.int64)
+    out["phase4_flat"] = torch.cat(r4).numpy()
+    save("geometry", **out)
+
+
+def gen_schedule():
+    from terrain_diffusion.scheduler.dpmsolver import EDMDPMSolverMultistepScheduler
+    from oracle import rng
+    out = {}
+    for n in (4, 12, 20, 32):
+        sch = EDMDPMSolverMultistepScheduler(sigma_min=0.002, sigma_max=80.0, sigma_data=0.5)
+        sch.set_timesteps(n)
+        out[f"sigmas_{n}"] = sch.sigmas.numpy()
+        out[f"timesteps_{n}"] = sch.timesteps.numpy()
+        # full step trace with a synthetic deterministic "model": F = tanh(0.3*x_in) - 0.2*cos(cn)
+        x = torch.from_numpy(rng.standard_normal(900 + n, (2, 5, 8, 8))) * sch.sigmas[0]
+        trace, orders = [], []
+        for t, sigma in zip(sch.timesteps, sch.sigmas):
+            xin = sch.precondition_inputs(x, sigma)
+            cn = sch.trigflow_precondition_noise(sigma.view(-1))
+            F_ = torch.tanh(0.3 * xin) - 0.2 * torch.cos(cn)
+            before = sch.lower_order_nums
+            x = sch.step(F_, t, x).prev_sample
+            trace.append(x.numpy().copy())
+        out[f"trace_{n}"] = np.stack(trace)
+        out[f"trigflow_t_{n}"] = sch.trigflow_precondition_noise(sch.sigmas[:-1]).numpy()
+    save("schedule", **out)
+
+
+def _ref_model(cfg, sd):
+    from terrain_diffusion.models.edm_unet import EDMUnet2D
+    m = EDMUnet2D(**cfg)
+    msd = m.state_dict()
+    from oracle.unet import param_shapes
+    ours = param_shapes(cfg)
+    ref_names = {k for k in msd if not k.startswith("logvar_")}
+    assert ref_names == set(ours) | {"noise_fourier.freqs"}, (ref_names ^ (set(ours) | {"noise_fourier.freqs"}))
+    for k, shp in ours.items():
+        assert tuple(msd[k].shape) == tuple(shp), (k, msd[k].shape, shp)
+    assert torch.equal(msd["noise_fourier.freqs"], sd["noise_fourier.freqs"]), "positional freqs restatement differs"
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("logvar_") for k in missing), (missing, unexpected)
+    return m.eval()
+
+
+def gen_unet():
+    from oracle import rng
+    from oracle.unet import BASE_CONFIG, tiny_config, synth_state_dict
+    out = {}
+    # --- tiny model: every block variant (enc/dec, skip conv, down/up, mid attention), B=2, 16x16
+    cfg = tiny_config(64, 1)
+    sd = synth_state_dict(cfg, seed=77)
+    m = _ref_model(cfg, sd)
+    x = torch.from_numpy(rng.standard_normal(7, (2, 5, 16, 16)))
+    t = torch.tensor([1.2, 0.3])
+    cond = torch.from_numpy(rng.standard_normal(8, (2, 58)))
+    taps = {}
+    hooks = []
+    for name, mod in list(m.enc.items()):
+        hooks.append(mod.register_forward_hook(lambda _m, _i, o, n="enc." + name: taps.__setitem__(n, o.detach().numpy().copy())))
+    for name, mod in list(m.dec.items()):
+        hooks.append(mod.register_forward_hook(lambda _m, _i, o, n="dec." + name: taps.__setitem__(n, o.detach().numpy().copy())))
+    with torch.no_grad():
+        y = m(x, noise_labels=t, conditional_inputs=[cond])
+        emb = m.compute_embeddings(t, [cond])
+    out["tiny_out"] = y.numpy()
+    out["tiny_emb"] = emb.numpy()
+    for k, v in taps.items():
+        out["tiny_tap:" + k] = v
+    # --- tiny model with 2 layers per block and attention at an encoder level too (attn_resolutions hits res name 128)
+    cfg2 = tiny_config(64, 2, attn_resolutions=[128])
+    sd2 = synth_state_dict(cfg2, seed=78)
+    m2 = _ref_model(cfg2, sd2)
+    x2 = torch.from_numpy(rng.standard_normal(9, (1, 5, 32, 32)))
+    with torch.no_grad():
+        out["tiny2_out"] = m2(x2, noise_labels=torch.tensor([0.9]), conditional_inputs=[torch.from_numpy(rng.standard_normal(10, (1, 58)))]).numpy()
+    # --- full-size base model (configs/diffusion_base/30m/diffusion_192-3.cfg:54-68), one forward, B=1, 64x64
+    cfgb = dict(BASE_CONFIG)
+    sdb = synth_state_dict(cfgb, seed=1234)
+    mb = _ref_model(cfgb, sdb)
+    xb = torch.from_numpy(rng.standard_normal(7, (1, 5, 64, 64)))
+    cb = torch.from_numpy(rng.standard_normal(8, (1, 58)))
+    with torch.no_grad():
+        yb = mb(xb, noise_labels=torch.tensor([1.1]), conditional_inputs=[cb])
+    out["base_out"] = yb.numpy()
+    print("base forward rms", float(yb.pow(2).mean().sqrt()))
+    save("unet", **out)
+
+
+def gen_sampling():
+    from terrain_diffusion.scheduler.dpmsolver import EDMDPMSolverMultistepScheduler
+    from terrain_diffusion.training.evaluation import sample_diffusion_base as sdb_mod
+    from oracle import rng, tiling
+    from oracle.unet import BASE_CONFIG, tiny_config, synth_state_dict
+    out = {}
+    cfg = tiny_config(64, 1)
+    sd = synth_state_dict(cfg, seed=77)
+    m = _ref_model(cfg, sd)
+    sch = EDMDPMSolverMultistepScheduler(sigma_min=0.002, sigma_max=80.0, sigma_data=0.5)
+
+    # _process_cond_img on NaN-free input
+    cond_img = torch.from_numpy(rng.standard_normal(31, (2, 7, 4, 4)))
+    means = torch.tensor([0.1, -0.2, 0.3, 0.0, 1.0, -1.0, 0.0])
+    stds = torch.tensor([1.0, 2.0, 0.5, 1.5, 1.0, 3.0, 1.0])
+    out["cond58"] = sdb_mod._process_cond_img(cond_img.clone(), torch.tensor([[0.1, 0.2, 0.3, 0.4, 0.5]]).expand(2, -1), means, stds, torch.full((2,), 0.25)).numpy()
+    out["cond58_zero"] = sdb_mod._process_cond_img(cond_img[:1].clone(), torch.zeros(1, 5), torch.zeros(7), torch.ones(7), torch.tensor(0.0)).numpy()
+
+    # reference uses torch.randn for the initial field; substitute the portable absolute-coordinate field
+    # (what the pipeline does via gaussian_noise_patch) so CPU and GPU see identical noise.
+    real_randn = torch.randn
+
+    def run_tiled(model, H, W, steps, tile, seed):
+        def fake_randn(shape, generator=None, device=None, dtype=None):
+            assert tuple(shape) == (1, 5, H, W)
+            return tiling.initial_noise_field(seed, H, W, 5)
+        torch.randn = fake_randn
+        try:
+            cond = tiling.synthetic_cond_grid(len(tiling.tile_starts(H, tile, tile // 2)), len(tiling.tile_starts(W, tile, tile // 2)))
+            return sdb_mod.sample_base_diffusion(model, sch, (1, 5, H, W), cond, cond_means=torch.zeros(7), cond_stds=torch.ones(7),
+                                                 noise_level=torch.tensor(0.0), histogram_raw=torch.zeros(1, 5), steps=steps, tile_size=tile)
+        finally:
+            torch.randn = real_randn
+
+    # tiny model, 3x3 tiles of 16 (stride 8) on a 32x32 canvas, 6 steps (N<15 order rule) and 16 steps
+    out["tiny_grid3_steps6"] = run_tiled(m, 32, 32, 6, 16, 42 + 5819).numpy()
+    out["tiny_grid3_steps16"] = run_tiled(m, 32, 32, 16, 16, 42 + 5819).numpy()
+    # ragged canvas: 40x24 -> starts [0,8,16,24] x [0,8] (last start clamped)
+    out["tiny_ragged_40x24_steps5"] = run_tiled(m, 40, 24, 5, 16, 99).numpy()
+
+    # consistency sampler, 2 phases, explicit noise (reference accepts `noise=`)
+    noise = [tiling.initial_noise_field(42 + 5819 + k, 32, 32, 5) for k in range(2)]
+    cond = tiling.synthetic_cond_grid(3, 3)
+    out["tiny_consistency_2phase"] = sdb_mod.sample_base_consistency(
+        m, sch, (1, 5, 32, 32), cond, cond_means=torch.zeros(7), cond_stds=torch.ones(7), noise_level=torch.tensor(0.0),
+        histogram_raw=torch.zeros(1, 5), intermediate_t=float(np.arctan(0.35 / 0.5)), tile_size=16, noise=noise).detach().numpy()
+
+    # BASELINE config 2: full-size base model, single 64x64 tile, 20 steps
+    cfgb = dict(BASE_CONFIG)
+    mb = _ref_model(cfgb, synth_state_dict(cfgb, seed=1234))
+    import time
+    t0 = time.time()
+    out["base_tile_steps20"] = run_tiled(mb, 64, 64, 20, 64, 42 + 5819).numpy()
+    print(f"reference base tile x20 steps: {time.time() - t0:.1f}s on {torch.get_num_threads()} threads")
+    save("sampling", **out)
+
+
+ALL = dict(rng=gen_rng, geometry=gen_geometry, schedule=gen_schedule, unet=gen_unet, sampling=gen_sampling)
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "golden generation needs the reference checkout"
+    install_shim()
+    torch.manual_seed(0)
+    for k in (sys.argv[1:] or list(ALL)):
+        ALL[k]()

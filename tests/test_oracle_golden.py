@@ -1,0 +1,206 @@
+"""CPU: pins the oracle (oracle/) to the golden vectors captured from the reference's own modules.
+
+Bit-exact: PCG stream, tile seeds, noise patches (C restatement built with -ffp-contract=off), tile
+starts, phase partition, blend windows, sigma schedule.  fp32 tolerance (stated per test): U-Net
+forward and sampler traces (different but equivalent op order: folded weights, fused coefficients).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_rms
+from oracle import rng, schedule, tiling
+from oracle.unet import BASE_CONFIG, OracleUnet, synth_state_dict, tiny_config
+
+
+# ------------------------------------------------------------------ integer / byte exact
+def test_pcg_stream_bit_exact(golden):
+    g = golden("rng")
+    for seed, ref in zip(g["stream_seeds"], g["streams"]):
+        assert np.array_equal(rng.pcg_stream(int(seed), 64), ref)
+        s, outs = int(seed), []
+        for _ in range(64):
+            s, u = rng.pcg_next_py(s)
+            outs.append(u)
+        assert np.array_equal(np.array(outs, dtype=np.uint32), ref)
+    for a, b in zip(g["next_seed_in"], g["next_seed_out"]):
+        assert rng.next_seed(int(a)) == int(b) == rng.next_seed_py(int(a))
+
+
+def test_tile_seed_bit_exact(golden):
+    g = golden("rng")
+    for (seed, _, _), (ty, tx), ref in zip(g["tile_seed_in"], g["tile_seed_in_signed"], g["tile_seed_out"]):
+        assert rng.tile_seed(int(seed), int(ty), int(tx)) == int(ref)
+        assert rng.tile_seed_py(int(seed), int(ty), int(tx)) == int(ref)
+
+
+def test_normals_bit_exact(golden):
+    g = golden("rng")
+    assert np.array_equal(rng.standard_normal(123, (4097,)), g["normal_seed123_n4097"])
+    assert np.array_equal(rng.standard_normal_py(123, 257), g["normal_seed123_n4097"][:257])
+    assert np.array_equal(rng.standard_normal(7, (33,), dtype=np.float64), g["normal_seed7_f64_n33"])
+    assert rng.standard_normal(5, (0,)).size == 0
+
+
+def test_noise_patches_bit_exact(golden):
+    g = golden("rng")
+    assert np.array_equal(rng.gaussian_noise_patch(42, -32, 32, 64, 64, 5, 64, 64), g["patch_latent_m32_32"])
+    assert np.array_equal(rng.gaussian_noise_patch(42 + 5819, 128, -64, 64, 64, 5, 64, 64), g["patch_latent_aligned"])
+    assert np.array_equal(rng.gaussian_noise_patch(43, 48, -96, 64, 64, 6, 64, 64), g["patch_coarse_48_m96"])
+    assert np.array_equal(rng.gaussian_noise_patch(7, -3, 61, 7, 9, 2, 16, 32), g["patch_small"])
+    assert np.array_equal(rng.gaussian_noise_patch(7, -1, -1, 1, 1, 1, 8, 8), g["patch_1x1"])
+    dec = rng.gaussian_noise_patch(42 + 5819, 384, -384, 512, 512, 1, 512, 512)
+    assert np.array_equal(dec.ravel()[::37], g["patch_decoder_stride37"])
+    assert np.allclose([dec.astype(np.float64).sum(), np.abs(dec.astype(np.float64)).sum()], g["patch_decoder_sum"], rtol=0, atol=1e-9)
+
+
+def test_noise_field_window_consistency():
+    """overlapping windows agree on the overlap — size-independent property."""
+    a = rng.gaussian_noise_patch(9, -40, -40, 96, 96, 3, 64, 64)
+    b = rng.gaussian_noise_patch(9, -8, 8, 64, 48, 3, 64, 64)
+    assert np.array_equal(a[:, 32:96, 48:96], b)
+
+
+def test_geometry_exact(golden):
+    g = golden("geometry")
+    for s in (4, 16, 64, 512):
+        assert np.array_equal(tiling.linear_weight_window(s).numpy(), g[f"lww_{s}"])
+    assert np.array_equal(tiling.pano_linear_kernel(64, 64).numpy(), g["pano_kernel_64"])
+    assert np.array_equal(tiling.pano_linear_kernel(8, 512).numpy(), g["pano_kernel_8x512"])
+    flat, pos = g["tile_starts_flat"], 0
+    for case, n in zip(g["tile_starts_cases"], g["tile_starts_len"]):
+        assert tiling.tile_starts(*[int(v) for v in case]) == [int(v) for v in flat[pos:pos + n]]
+        pos += n
+    ranges = tiling.build_timestep_ranges(torch.from_numpy(g["ddim_timesteps"]), (400, 600, 750, 900))
+    assert [len(r) for r in ranges] == list(g["phase_len"])
+    assert np.array_equal(torch.cat(ranges).numpy(), g["phase_flat"])
+    r4 = tiling.build_timestep_ranges(torch.tensor([751, 501, 251, 1]), (400, 600, 750, 900))
+    assert [len(r) for r in r4] == list(g["phase4_len"]) and np.array_equal(torch.cat(r4).numpy(), g["phase4_flat"])
+
+
+def test_interior_weight_sum_constant():
+    """stride s/2 window sums are the constant (2-0.999*(s/2)/m)^2 in the interior."""
+    w = tiling.linear_weight_window(64).double()
+    acc = torch.zeros(128, 128, dtype=torch.float64)
+    for i in (0, 32, 64):
+        for j in (0, 32, 64):
+            acc[i:i + 64, j:j + 64] += w
+    c = (2 - 0.999 * 32 / 31.5) ** 2
+    assert torch.allclose(acc[32:96, 32:96], torch.full((64, 64), c, dtype=torch.float64), atol=1e-6)
+
+
+def test_schedule_bit_exact(golden):
+    g = golden("schedule")
+    for n in (4, 12, 20, 32):
+        sig, ts = schedule.karras_sigmas(n)
+        assert np.array_equal(sig.numpy(), g[f"sigmas_{n}"])
+        assert np.array_equal(ts.numpy(), g[f"timesteps_{n}"])
+        assert np.array_equal(schedule.trigflow_t(sig[:-1]).numpy(), g[f"trigflow_t_{n}"])
+    assert schedule.solver_orders(20) == [1] + [2] * 18 + [1]
+    # NB: with solver_order=2 the `lower_order_second` clause (dpmsolver.py:694-696) is unreachable: the
+    # elif at :711 tests `solver_order == 2` first, so N<15 does NOT force a 1st-order penultimate step.
+    assert schedule.solver_orders(4) == [1, 2, 2, 1]
+    assert schedule.solver_orders(12) == [1] + [2] * 10 + [1]
+
+
+def test_solver_trace(golden):
+    """explicit-counter restatement of scheduler.step reproduces the stateful reference trace.
+    Tolerance: 2e-6 relative (fp32; identical op order term by term, so normally 0)."""
+    g = golden("schedule")
+    for n in (4, 12, 20, 32):
+        sig, _ = schedule.karras_sigmas(n)
+        orders = schedule.solver_orders(n)
+        x = torch.from_numpy(rng.standard_normal(900 + n, (2, 5, 8, 8))) * sig[0]
+        m_prev = None
+        for i in range(n):
+            xin = schedule.precondition_inputs(x, sig[i])
+            cn = schedule.trigflow_t(sig[i].view(-1))
+            F_ = torch.tanh(0.3 * xin) - 0.2 * torch.cos(cn)
+            x, m_prev = schedule.dpm_step(sig, i, orders[i], x, F_, m_prev)
+            assert rel_rms(x.numpy(), g[f"trace_{n}"][i]) < 2e-6, (n, i)
+
+
+# ------------------------------------------------------------------ floating point
+def test_cond_vector(golden):
+    g = golden("sampling")
+    cond_img = torch.from_numpy(rng.standard_normal(31, (2, 7, 4, 4)))
+    means = torch.tensor([0.1, -0.2, 0.3, 0.0, 1.0, -1.0, 0.0])
+    stds = torch.tensor([1.0, 2.0, 0.5, 1.5, 1.0, 3.0, 1.0])
+    got = tiling.process_cond_img(cond_img, torch.tensor([[0.1, 0.2, 0.3, 0.4, 0.5]]), means, stds, torch.full((2,), 0.25))
+    assert got.shape == (2, 58) and np.allclose(got.numpy(), g["cond58"], rtol=1e-6, atol=1e-6)
+    got0 = tiling.process_cond_img(cond_img[:1], torch.zeros(1, 5), torch.zeros(7), torch.ones(7), 0.0)
+    assert np.allclose(got0.numpy(), g["cond58_zero"], rtol=1e-6, atol=1e-6)
+
+
+def test_unet_tiny_vs_reference(golden):
+    """tolerance 5e-6 rel-RMS per tensor (fp32 vs fp32, folded weights): reference fp32-vs-fp64 is 4.7e-7."""
+    g = golden("unet")
+    cfg = tiny_config(64, 1)
+    m = OracleUnet(cfg, synth_state_dict(cfg, seed=77))
+    x = torch.from_numpy(rng.standard_normal(7, (2, 5, 16, 16)))
+    t = torch.tensor([1.2, 0.3])
+    cond = torch.from_numpy(rng.standard_normal(8, (2, 58)))
+    taps = {}
+    with torch.no_grad():
+        y = m(x, t, [cond], taps=taps)
+        emb = m.embeddings(t, [cond])
+    assert rel_rms(emb.numpy(), g["tiny_emb"]) < 5e-6
+    n_checked = 0
+    for k in g.files:
+        if k.startswith("tiny_tap:"):
+            assert rel_rms(taps[k[len("tiny_tap:"):]].numpy(), g[k]) < 5e-6, k
+            n_checked += 1
+    assert n_checked == len(m.plan["enc"]) + len(m.plan["dec"])
+    assert rel_rms(y.numpy(), g["tiny_out"]) < 5e-6
+    assert float(np.sqrt((g["tiny_out"] ** 2).mean())) > 0.1  # non-vacuous
+
+
+def test_unet_tiny2_encoder_attention(golden):
+    g = golden("unet")
+    cfg = tiny_config(64, 2, attn_resolutions=[128])
+    m = OracleUnet(cfg, synth_state_dict(cfg, seed=78))
+    x = torch.from_numpy(rng.standard_normal(9, (1, 5, 32, 32)))
+    with torch.no_grad():
+        y = m(x, torch.tensor([0.9]), [torch.from_numpy(rng.standard_normal(10, (1, 58)))])
+    assert rel_rms(y.numpy(), g["tiny2_out"]) < 5e-6
+
+
+@pytest.mark.slow
+def test_unet_base_vs_reference(golden):
+    g = golden("unet")
+    m = OracleUnet(BASE_CONFIG, synth_state_dict(BASE_CONFIG, seed=1234))
+    x = torch.from_numpy(rng.standard_normal(7, (1, 5, 64, 64)))
+    with torch.no_grad():
+        y = m(x, torch.tensor([1.1]), [torch.from_numpy(rng.standard_normal(8, (1, 58)))])
+    assert rel_rms(y.numpy(), g["base_out"]) < 5e-6
+
+
+def test_tiled_sampler_tiny(golden):
+    """bounded tiled EDM sampler (3x3 tiles, ragged canvas) — tolerance 2e-5 rel-RMS after <=16 steps."""
+    g = golden("sampling")
+    cfg = tiny_config(64, 1)
+    m = OracleUnet(cfg, synth_state_dict(cfg, seed=77))
+    for key, (H, W, steps, seed) in {"tiny_grid3_steps6": (32, 32, 6, 42 + 5819), "tiny_grid3_steps16": (32, 32, 16, 42 + 5819),
+                                     "tiny_ragged_40x24_steps5": (40, 24, 5, 99)}.items():
+        cond = tiling.synthetic_cond_grid(len(tiling.tile_starts(H, 16, 8)), len(tiling.tile_starts(W, 16, 8)))
+        y = tiling.sample_base_diffusion_tiled(m, (1, 5, H, W), cond, steps=steps, tile_size=16, noise_seed=seed)
+        assert rel_rms(y.numpy(), g[key]) < 2e-5, key
+
+
+def test_consistency_sampler_tiny(golden):
+    g = golden("sampling")
+    cfg = tiny_config(64, 1)
+    m = OracleUnet(cfg, synth_state_dict(cfg, seed=77))
+    y = tiling.sample_base_consistency_tiled(m, (1, 5, 32, 32), tiling.synthetic_cond_grid(3, 3),
+                                             intermediate_t=float(np.arctan(0.35 / 0.5)), tile_size=16)
+    assert rel_rms(y.numpy(), g["tiny_consistency_2phase"]) < 1e-5
+
+
+@pytest.mark.slow
+def test_base_tile_20_steps(golden):
+    """BASELINE config 2 through the oracle vs the reference's sample_base_diffusion — tolerance 2e-5 rel-RMS
+    (reference fp32-vs-fp64 after 20 steps is 3.0e-7; the oracle folds weights once, so op order differs)."""
+    g = golden("sampling")
+    m = OracleUnet(BASE_CONFIG, synth_state_dict(BASE_CONFIG, seed=1234))
+    y = tiling.sample_base_diffusion_tiled(m, (1, 5, 64, 64), tiling.synthetic_cond_grid(1, 1), steps=20, tile_size=64)
+    assert rel_rms(y.numpy(), g["base_tile_steps20"]) < 2e-5
