@@ -1,0 +1,117 @@
+/*
+ * td_engine.h — C-ABI of the MI355X-native InfiniteDiffusion sampling engine (libtd_engine.so).
+ *
+ * The reference (xandergos/terrain-diffusion) is pure Python and has no FFI; its boundary for this path
+ * is the Python operator surface listed in SURVEY.md §8b.  Each entry point below names the reference
+ * interface it replaces (paths relative to the reference checkout).  INTEGRATION.md shows the ctypes
+ * binding a maintainer would add on the reference side.
+ *
+ * Conventions: plain C, opaque handles, return 0 on success / negative code on failure with a message in
+ * td_last_error().  One engine per GPU, single caller thread per handle (the reference's servers run
+ * threaded=False: terrain_diffusion/inference/api.py:249).  Tensor arguments are raw pointers; unless a
+ * parameter says "host", a pointer may be device OR host memory (detected with hipPointerGetAttributes;
+ * host buffers are staged through the engine's stream).  All tensors are fp32 in the reference's layouts
+ * (NCHW tiles, (C+1,H,W) canvases); bf16 exists only inside the engine.
+ */
+#ifndef TD_ENGINE_H
+#define TD_ENGINE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct td_engine td_engine;
+typedef struct td_unet td_unet;
+
+enum { TD_OK = 0, TD_ERR_ARG = -1, TD_ERR_HIP = -2, TD_ERR_STATE = -3, TD_ERR_UNSUPPORTED = -4 };
+enum { TD_DTYPE_F32 = 0, TD_DTYPE_BF16 = 1 };
+
+/* EDMUnet2D constructor arguments that shape the inference graph
+ * (terrain_diffusion/models/edm_unet.py:17-37).  `cond_dim` describes the single ["tensor", cond_dim, w]
+ * conditional input of the base model (configs/diffusion_base/30m/diffusion_192-3.cfg:66); 0 = none. */
+typedef struct td_unet_config {
+    int32_t image_size;            /* only used for block names / attention resolution test */
+    int32_t in_channels, out_channels;
+    int32_t model_channels;
+    int32_t n_levels;
+    int32_t channel_mults[8];
+    int32_t layers_per_block[8];
+    int32_t n_attn_resolutions;
+    int32_t attn_resolutions[8];
+    int32_t midblock_attention;
+    float concat_balance;
+    int32_t noise_emb_dims;        /* 0 -> model_channels */
+    int32_t emb_channels;          /* 0 -> model_channels * max(mults) */
+    int32_t cond_dim;
+    float cond_weight;
+} td_unet_config;
+
+const char* td_last_error(void);
+int td_version(void);
+
+/* ---- engine ----------------------------------------------------------------------------------------------- */
+int td_engine_create(int device_id, td_engine** out);
+void td_engine_destroy(td_engine* e);
+int td_engine_synchronize(td_engine* e);
+/* raw hipStream_t the engine launches on (for timing with HIP events on the right stream) */
+void* td_engine_stream(td_engine* e);
+/* tuning knobs, e.g. "splitk"=0/1, "graph"=0/1, "bn128_min_wgs"=N */
+int td_engine_set_option(td_engine* e, const char* key, int64_t value);
+
+/* ---- model ------------------------------------------------------------------------------------------------
+ * Replaces EDMUnet2D(...) + load_state_dict (edm_unet.py:17-143; diffusers layout, SURVEY.md §8b face 3).
+ * Weights are the reference's RAW fp32 parameters by state-dict name; the engine folds the magnitude-preserving
+ * normalisation once (mp_layers.py:203-213) and packs them for the MFMA kernels. */
+int td_unet_create(td_engine* e, const td_unet_config* cfg, int dtype, td_unet** out);
+void td_unet_destroy(td_unet* u);
+int td_unet_num_params(td_unet* u);
+/* i-th expected parameter: name and shape (ndim<=4) — lets the caller validate a checkpoint */
+int td_unet_param_info(td_unet* u, int i, const char** name, int32_t* ndim, int64_t shape[4]);
+int td_unet_set_param(td_unet* u, const char* name, const float* host_data, int64_t numel);
+int td_unet_finalize(td_unet* u);
+
+/* model(x, noise_labels=t, conditional_inputs=[cond]) -> F      (edm_unet.py:161-184)
+ * x: [n][in_channels][H][W], t: host [n], cond: [n][cond_dim], out: [n][out_channels][H][W] */
+int td_unet_forward(td_unet* u, int n, int H, int W, const float* x, const float* t_host, const float* cond, float* out);
+
+/* ---- portable noise (terrain_diffusion/inference/portable_rng.py:22-89, world_pipeline.py:58-115) ---------- */
+uint64_t td_tile_seed(uint64_t base_seed, int64_t ty, int64_t tx);                 /* _tile_seed */
+int td_standard_normal(td_engine* e, uint64_t seed, int64_t n, float* out);        /* standard_normal(seed, n) */
+/* gaussian_noise_patch for `n_windows` windows of (channels,h,w) at origins[2*i]=(y0,x0) (host int64 pairs) */
+int td_noise_patches(td_engine* e, uint64_t base_seed, int n_windows, const int64_t* origins_host, int h, int w,
+                     int channels, int tile_h, int tile_w, float scale, float* out);
+
+/* ---- schedule (terrain_diffusion/scheduler/dpmsolver.py:285-342) — host ------------------------------------ */
+int td_schedule_karras(int n, float sigma_min, float sigma_max, float rho, float* sigmas_out /*n+1*/, float* timesteps_out /*n*/);
+
+/* ---- samplers ---------------------------------------------------------------------------------------------
+ * Inner loop of sample_base_diffusion (terrain_diffusion/training/evaluation/sample_diffusion_base.py:147-162)
+ * and _coarse_inference (world_pipeline.py:941-949) for a batch of independent tiles:
+ *   for i in steps: F = model(c_in*x, atan(sigma_i/sigma_d), cond); x = DPMSolver++(2M).step(F, x)
+ * x: in/out [n][C][H][W] (enter as noise*sigma_0, leave as the sigma=0 sample, NOT divided by sigma_data).
+ * sigmas_host: n_steps+1 values (last = 0). */
+int td_sample_edm(td_unet* u, int n, int H, int W, int n_steps, const float* sigmas_host, float sigma_data,
+                  const float* cond, float* x);
+/* One trig-flow consistency phase (sample_diffusion_base.py:248-257, world_pipeline.py:1097-1129):
+ *   x_t = cos t*sample + sin t*sigma_d*z ; out = cos t*x_t + sin t*sigma_d*model(x_t/sigma_d, t, cond)
+ * sample may be NULL (zeros, first phase). */
+int td_sample_consistency(td_unet* u, int n, int H, int W, float t, float sigma_data, const float* sample, const float* z,
+                          const float* cond, float* out);
+
+/* ---- overlap blend (sample_diffusion_base.py:164-168; annotated_infinite_panorama.py:145-150) ----------------
+ * canvas: (C+1, Hc, Wc) fp32, weighted sums + weight channel.  Adds window i (tiles[i] = [C][size][size]) at
+ * (row_starts[wi[i]], col_starts[wj[i]]) with the linear weight window, summing in ascending (wi,wj) order
+ * (the reference's loop order) so results are bit-reproducible.  accumulate=0 overwrites the canvas. */
+int td_blend_windows(td_engine* e, float* canvas, int C, int Hc, int Wc, int size, int n_rows, const int32_t* row_starts_host,
+                     int n_cols, const int32_t* col_starts_host, int n_tiles, const int32_t* wi_host, const int32_t* wj_host,
+                     const float* tiles, int accumulate);
+/* out[c] = canvas[c]/canvas[C]*scale, out: (C,Hc,Wc) */
+int td_blend_normalize(td_engine* e, const float* canvas, int C, int Hc, int Wc, float scale, float* out);
+/* linear_weight_window(size) (world_pipeline.py:117-124) -> out[size*size] */
+int td_linear_weight_window(td_engine* e, int size, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

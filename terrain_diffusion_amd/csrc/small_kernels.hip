@@ -1,0 +1,377 @@
+// Small / memory-bound kernels of the sampling path (gfx950): embeddings, attention core, scheduler step,
+// portable-RNG noise field, overlap blend, layout conversion.  Each cites the reference lines it replaces.
+#include "td_device.h"
+
+namespace td {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float mp_silu_acc(float x) { return x / (1.f + expf(-x)) * (1.f / 0.596f); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ embeddings
+// edm_unet.py:145-159 + mp_layers.py:96-107: emb[row] = mp_silu( (noise_linear(posemb(t)) + w_c*mp_silu(cond_linear(cond))) / ||w|| )
+// rows = (step, tile); t depends on step only, cond on tile only.  One workgroup per row, one wave per output.
+__global__ __launch_bounds__(256) void emb_kernel(const float* __restrict__ t_steps, const float* __restrict__ cond, int n_tiles,
+                                                  const float* __restrict__ freqs, int half, const float* __restrict__ w_noise,
+                                                  const float* __restrict__ w_cond, int cond_dim, float cond_weight, int emb_ch,
+                                                  float* __restrict__ emb) {
+    extern __shared__ float sh[];  // posemb[2*half] + cond[cond_dim]
+    const int row = blockIdx.x, step = row / n_tiles, tile = row % n_tiles;
+    const float t = t_steps[step];
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        float y = t * freqs[i];
+        sh[i] = sinf(y) * 1.41421356237309515f;
+        sh[half + i] = cosf(y) * 1.41421356237309515f;
+    }
+    for (int i = threadIdx.x; i < cond_dim; i += blockDim.x) sh[2 * half + i] = cond[(size_t)tile * cond_dim + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nd = 2 * half;
+    const float inv_norm = 1.f / sqrtf(1.f + (cond_dim > 0 ? cond_weight * cond_weight : 0.f));
+    for (int j = wave; j < emb_ch; j += blockDim.x / 64) {
+        float a = 0.f;
+        for (int k = lane; k < nd; k += 64) a += w_noise[(size_t)j * nd + k] * sh[k];
+        a = wave_sum(a);
+        float b = 0.f;
+        if (cond_dim > 0) {
+            for (int k = lane; k < cond_dim; k += 64) b += w_cond[(size_t)j * cond_dim + k] * sh[nd + k];
+            b = mp_silu_acc(wave_sum(b));
+        }
+        if (lane == 0) emb[(size_t)row * emb_ch + j] = mp_silu_acc((a + cond_weight * b) * inv_norm);
+    }
+}
+
+// unet_block.py:129-131: c = emb_linear(emb)*gain + 1 (gain folded into w).  grid (co tiles of 64, rows of 16, block index).
+__global__ __launch_bounds__(256) void cvec_kernel(const float* __restrict__ emb, int rows, int emb_ch, const float* __restrict__ w_all,
+                                                   const int* __restrict__ blk_woff, const int* __restrict__ blk_coff,
+                                                   const int* __restrict__ blk_cout, int c_total, float* __restrict__ craw) {
+    extern __shared__ float sh[];  // [16][emb_ch]
+    const int blk = blockIdx.z, cout = blk_cout[blk];
+    const int co_base = blockIdx.x * 64;
+    if (co_base >= cout) return;
+    const int r0 = blockIdx.y * 16, nr = min(16, rows - r0);
+    for (int i = threadIdx.x; i < nr * emb_ch; i += blockDim.x) sh[i] = emb[(size_t)r0 * emb_ch + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* w = w_all + blk_woff[blk];
+    for (int c = wave; c < 64; c += 4) {
+        const int co = co_base + c;
+        if (co >= cout) break;
+        float acc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int k = lane; k < emb_ch; k += 64) {
+            float wv = w[(size_t)co * emb_ch + k];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += wv * sh[r * emb_ch + k];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = wave_sum(acc[r]);
+            if (lane == 0 && r < nr) craw[(size_t)(r0 + r) * c_total + blk_coff[blk] + co] = s + 1.f;
+        }
+    }
+}
+
+// c /= sqrt(mean(c^2) + 1e-8) per (row, block).  grid (rows, blocks)
+__global__ __launch_bounds__(256) void cvec_norm_kernel(float* __restrict__ c, const int* __restrict__ blk_coff, const int* __restrict__ blk_cout, int c_total) {
+    __shared__ float red[4];
+    const int blk = blockIdx.y, cout = blk_cout[blk];
+    float* v = c + (size_t)blockIdx.x * c_total + blk_coff[blk];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < cout; i += blockDim.x) s += v[i] * v[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float inv = 1.f / sqrtf(tot / (float)cout + 1e-8f);
+    for (int i = threadIdx.x; i < cout; i += blockDim.x) v[i] *= inv;
+}
+
+// ------------------------------------------------------------------------------------------------ attention core
+// unet_block.py:102-108.  qkv is NHWC with channel = (head*64 + c)*3 + {q,k,v}; per-token unit-RMS norm of q,k,v over c,
+// logits/sqrt(64), softmax over keys, out[token][head*64 + c].  One workgroup per (image, head); tokens <= 64.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens, int C) {
+    __shared__ float sq[64][65], sk[64][65], sv[64][65], sw[64][65];
+    const int n = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
+    const size_t base = (size_t)n * tokens * 3 * C;
+    for (int e = tid; e < tokens * 64; e += 256) {
+        int tok = e >> 6, c = e & 63;
+        const T* ptr = qkv + base + (size_t)tok * 3 * C + (head * 64 + c) * 3;
+        sq[tok][c] = (float)ptr[0]; sk[tok][c] = (float)ptr[1]; sv[tok][c] = (float)ptr[2];
+    }
+    __syncthreads();
+    // normalize(y, dim=2): x / (1e-4 + ||x||_c / sqrt(64)), for q, k and v of every token
+    if (tid < 3 * 64) {
+        int which = tid >> 6, tok = tid & 63;
+        if (tok < tokens) {
+            float (*m)[65] = which == 0 ? sq : (which == 1 ? sk : sv);
+            float s = 0.f;
+            for (int c = 0; c < 64; ++c) s += m[tok][c] * m[tok][c];
+            float inv = 1.f / (1e-4f + sqrtf(s) * 0.125f);
+            if (which == 1) inv *= 0.125f;  // k / sqrt(64)
+            for (int c = 0; c < 64; ++c) m[tok][c] *= inv;
+        }
+    }
+    __syncthreads();
+    const int q = tid >> 2, part = tid & 3;  // 4 threads per query row
+    float mx = -3.0e38f;
+    if (q < tokens) {
+        for (int k = part; k < tokens; k += 4) {
+            float s = 0.f;
+            for (int c = 0; c < 64; ++c) s += sq[q][c] * sk[k][c];
+            sw[q][k] = s;
+            mx = fmaxf(mx, s);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
+    float den = 0.f;
+    if (q < tokens) {
+        for (int k = part; k < tokens; k += 4) { float e = expf(sw[q][k] - mx); sw[q][k] = e; den += e; }
+    }
+    den += __shfl_xor(den, 1); den += __shfl_xor(den, 2);
+    __syncthreads();
+    if (q < tokens) {
+        const float inv = 1.f / den;
+        for (int c = part * 16; c < part * 16 + 16; ++c) {
+            float s = 0.f;
+            for (int k = 0; k < tokens; ++k) s += sw[q][k] * sv[k][c];
+            out[((size_t)n * tokens + q) * C + head * 64 + c] = (T)(s * inv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ layout / scheduler
+// x: planar fp32 [N][C][HW]; xin: NHWC T [N][HW][cstride] = (x*scale, 1, 0...) — edm_unet.py:168 ones channel.
+template <typename T>
+__global__ void prep_input_kernel(const float* __restrict__ x, T* __restrict__ xin, int N, int C, int HW, int cstride, float scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * HW) return;
+    int n = (int)(i / HW), p = (int)(i % HW);
+    for (int c = 0; c < C; ++c) xin[i * cstride + c] = (T)(x[((size_t)n * C + c) * HW + p] * scale);
+    xin[i * cstride + C] = (T)1.f;
+}
+
+// F: NHWC fp32 [N][HW][fstride] -> planar [N][C][HW]
+__global__ void unpack_output_kernel(const float* __restrict__ F, float* __restrict__ y, int N, int C, int HW, int fstride, float scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * HW) return;
+    int n = (int)(i / HW), p = (int)(i % HW);
+    for (int c = 0; c < C; ++c) y[((size_t)n * C + c) * HW + p] = F[i * fstride + c] * scale;
+}
+
+// One DPM-Solver++(2M) step (dpmsolver.py:245-258, 454-561, 650-726) fused with the next step's input
+// preconditioning (dpmsolver.py:226-229).  x, m1 planar fp32 [N][C][HW]; F NHWC fp32.
+template <typename T>
+__global__ void dpm_step_kernel(float* __restrict__ x, float* __restrict__ m1, const float* __restrict__ F, T* __restrict__ xin,
+                                int N, int C, int HW, int fstride, int cstride, SchedCoef k) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * HW) return;
+    int n = (int)(i / HW), p = (int)(i % HW);
+    for (int c = 0; c < C; ++c) {
+        size_t xi = ((size_t)n * C + c) * HW + p;
+        float xs = x[xi];
+        float m0 = k.c_skip * xs + k.c_out * F[i * fstride + c];
+        float xn;
+        if (k.order == 1) {
+            xn = k.a * xs - k.b0 * m0;
+        } else {
+            float d1 = k.inv_r0 * (m0 - m1[xi]);
+            xn = k.a * xs - k.b0 * m0 - (0.5f * k.b0) * d1;
+        }
+        x[xi] = xn;
+        m1[xi] = m0;
+        if (!k.last) xin[i * cstride + c] = (T)(xn * k.c_in_next);
+    }
+}
+
+// Trig-flow consistency step (world_pipeline.py:1097-1129 / sample_diffusion_base.py:251-257):
+// pre:  x_t = cos t * sample + sin t * sigma_d * z ; xin = x_t / sigma_d ;  post: out = cos t * x_t - sin t * sigma_d * (-F)
+template <typename T>
+__global__ void consistency_pre_kernel(const float* __restrict__ sample, const float* __restrict__ z, float* __restrict__ xt, T* __restrict__ xin,
+                                       int N, int C, int HW, int cstride, float cos_t, float sin_t, float sigma_data) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * HW) return;
+    int n = (int)(i / HW), p = (int)(i % HW);
+    for (int c = 0; c < C; ++c) {
+        size_t xi = ((size_t)n * C + c) * HW + p;
+        float v = cos_t * sample[xi] + sin_t * (z[xi] * sigma_data);
+        xt[xi] = v;
+        xin[i * cstride + c] = (T)(v / sigma_data);
+    }
+    xin[i * cstride + C] = (T)1.f;
+}
+__global__ void consistency_post_kernel(const float* __restrict__ xt, const float* __restrict__ F, float* __restrict__ out, int N, int C, int HW,
+                                        int fstride, float cos_t, float sin_t, float sigma_data) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * HW) return;
+    int n = (int)(i / HW), p = (int)(i % HW);
+    for (int c = 0; c < C; ++c) {
+        size_t xi = ((size_t)n * C + c) * HW + p;
+        float pred = -F[i * fstride + c];
+        out[xi] = cos_t * xt[xi] - sin_t * sigma_data * pred;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ portable noise
+// portable_rng.py:22-74: 64-bit LCG, XSH-RR output of the post-advance state, Marsaglia polar with rejection.
+// Parallel form: thread t of a workgroup owns candidate pairs [round*R + t*PPT, +PPT) via LCG jump-ahead; accepted
+// pairs are compacted in candidate order with a block prefix scan, so the output equals the sequential stream.
+#define PCG_MULT 6364136223846793005ULL
+#define PCG_INC 1442695040888963407ULL
+
+__device__ __forceinline__ void lcg_jump(uint64_t n, uint64_t& mul, uint64_t& add) {
+    uint64_t cm = PCG_MULT, ca = PCG_INC;
+    mul = 1; add = 0;
+    while (n) {
+        if (n & 1) { mul *= cm; add = add * cm + ca; }
+        ca = (cm + 1) * ca; cm *= cm; n >>= 1;
+    }
+}
+__device__ __forceinline__ uint32_t pcg_out(uint64_t s) {
+    uint32_t x = (uint32_t)(((s >> 18) ^ s) >> 27), rot = (uint32_t)(s >> 59);
+    return (x >> rot) | (x << ((32u - rot) & 31u));
+}
+
+// one workgroup (256 threads) per noise tile; out[tile] has n floats
+__global__ __launch_bounds__(256) void noise_tiles_kernel(const uint64_t* __restrict__ seeds, float* __restrict__ out, int64_t n) {
+    constexpr int PPT = 8, NTH = 256, R = PPT * NTH;
+    __shared__ int s_scan[NTH];
+    __shared__ int s_base;
+    const int tid = threadIdx.x;
+    float* o = out + (size_t)blockIdx.x * n;
+    uint64_t jm, ja, rm, ra;
+    lcg_jump((uint64_t)(2 * PPT) * tid, jm, ja);
+    lcg_jump((uint64_t)(2 * R), rm, ra);
+    uint64_t state = seeds[blockIdx.x] * jm + ja;  // state before this thread's first candidate pair
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    const double inv = 1.0 / 4294967296.0;
+    while (true) {
+        const int base = s_base;  // accepted values so far
+        if (base >= n) break;
+        float v1o[PPT], v2o[PPT];
+        unsigned accept = 0;
+        uint64_t s = state;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            s = s * PCG_MULT + PCG_INC; uint32_t u1 = pcg_out(s);
+            s = s * PCG_MULT + PCG_INC; uint32_t u2 = pcg_out(s);
+            double v1 = 2.0 * ((double)u1 + 1.0) * inv - 1.0;
+            double v2 = 2.0 * ((double)u2 + 1.0) * inv - 1.0;
+            double r = v1 * v1 + v2 * v2;
+            if (r > 0.0 && r < 1.0) {
+                double f = sqrt(-2.0 * log(r) / r);
+                v1o[j] = (float)(v1 * f); v2o[j] = (float)(v2 * f);
+                accept |= 1u << j;
+            }
+        }
+        state = state * rm + ra;
+        const int cnt = __popc(accept);
+        s_scan[tid] = cnt;
+        __syncthreads();
+        for (int off = 1; off < NTH; off <<= 1) {  // Hillis-Steele inclusive scan
+            int v = (tid >= off) ? s_scan[tid - off] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        int64_t pos = base + 2 * (int64_t)(s_scan[tid] - cnt);
+        const int total = s_scan[NTH - 1];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            if (accept & (1u << j)) {
+                if (pos < n) o[pos] = v1o[j];
+                if (pos + 1 < n) o[pos + 1] = v2o[j];
+                pos += 2;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_base = base + 2 * total;
+        __syncthreads();
+    }
+}
+
+// window gather: out[win][c][y][x] = tile(ty,tx)[c][yy][xx] (world_pipeline.py:66-115); tile_index maps (win, dy, dx) of the
+// up-to-2x2 touched tiles to a slot in `tiles`.  scale multiplies the noise (e.g. sigma_0).
+__global__ void noise_gather_kernel(const float* __restrict__ tiles, const int* __restrict__ tile_index, const int* __restrict__ origins,
+                                    float* __restrict__ out, int C, int h, int w, int tile_h, int tile_w, float scale) {
+    const int win = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * h * w) return;
+    const int x = i % w, y = (i / w) % h, c = i / (w * h);
+    const int gy = origins[2 * win] + y, gx = origins[2 * win + 1] + x;
+    auto fdiv = [](int a, int b) { int q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; };
+    const int ty = fdiv(gy, tile_h), tx = fdiv(gx, tile_w);
+    const int ty0 = fdiv(origins[2 * win], tile_h), tx0 = fdiv(origins[2 * win + 1], tile_w);
+    const int slot = tile_index[win * 4 + (ty - ty0) * 2 + (tx - tx0)];
+    const int yy = gy - ty * tile_h, xx = gx - tx * tile_w;
+    out[(size_t)win * C * h * w + i] = tiles[((size_t)slot * C + c) * tile_h * tile_w + yy * tile_w + xx] * scale;
+}
+
+// ------------------------------------------------------------------------------------------------ overlap blend
+// sample_diffusion_base.py:164-168 / annotated_infinite_panorama.py:145-150.  Deterministic gather form: every canvas pixel sums its
+// covering windows in ascending (row-window, col-window) order, which is the reference's loop order, so the fp32 sum is bit-identical.
+// canvas: planar fp32 [(C+1)][Hc][Wc]; rowmap/colmap: per canvas row/col up to 4 covering window indices (-1 padded);
+// tile_of: window grid -> slot in x (or -1 if that window is not present in this launch).
+__global__ void blend_gather_kernel(const float* __restrict__ x, const float* __restrict__ wwin, float* __restrict__ canvas, int C, int Hc, int Wc,
+                                    int size, const int* __restrict__ rowmap, const int* __restrict__ colmap, const int* __restrict__ row_start,
+                                    const int* __restrict__ col_start, const int* __restrict__ tile_of, int n_wcols, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Hc * Wc) return;
+    const int y = i / Wc, xq = i % Wc;
+    float acc[8];
+    for (int c = 0; c <= C; ++c) acc[c] = accumulate ? canvas[(size_t)c * Hc * Wc + i] : 0.f;
+    for (int a = 0; a < 4; ++a) {
+        const int ic = rowmap[y * 4 + a];
+        if (ic < 0) continue;
+        for (int b = 0; b < 4; ++b) {
+            const int jc = colmap[xq * 4 + b];
+            if (jc < 0) continue;
+            const int slot = tile_of[ic * n_wcols + jc];
+            if (slot < 0) continue;
+            const int ly = y - row_start[ic], lx = xq - col_start[jc];
+            const float w = wwin[ly * size + lx];
+            for (int c = 0; c < C; ++c) acc[c] += x[(((size_t)slot * C + c) * size + ly) * size + lx] * w;
+            acc[C] += w;
+        }
+    }
+    for (int c = 0; c <= C; ++c) canvas[(size_t)c * Hc * Wc + i] = acc[c];
+}
+
+// out[c] = canvas[c] / canvas[C] * scale   (normalise-on-read)
+__global__ void blend_normalize_kernel(const float* __restrict__ canvas, float* __restrict__ out, int C, int HW, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const float wsum = canvas[(size_t)C * HW + i];
+    for (int c = 0; c < C; ++c) out[(size_t)c * HW + i] = canvas[(size_t)c * HW + i] / wsum * scale;
+}
+
+// window extraction from a normalised planar canvas into per-tile samples (phase input for multi-phase sampling)
+__global__ void window_extract_kernel(const float* __restrict__ img, float* __restrict__ tiles, const int* __restrict__ origins, int C, int Hc, int Wc, int size) {
+    const int win = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * size * size) return;
+    const int x = i % size, y = (i / size) % size, c = i / (size * size);
+    tiles[(size_t)win * C * size * size + i] = img[((size_t)c * Hc + origins[2 * win] + y) * Wc + origins[2 * win + 1] + x];
+}
+
+// explicit instantiations used by the engine
+template __global__ void attn_kernel<float>(const float*, float*, int, int);
+template __global__ void attn_kernel<__bf16>(const __bf16*, __bf16*, int, int);
+template __global__ void prep_input_kernel<float>(const float*, float*, int, int, int, int, float);
+template __global__ void prep_input_kernel<__bf16>(const float*, __bf16*, int, int, int, int, float);
+template __global__ void dpm_step_kernel<float>(float*, float*, const float*, float*, int, int, int, int, int, SchedCoef);
+template __global__ void dpm_step_kernel<__bf16>(float*, float*, const float*, __bf16*, int, int, int, int, int, SchedCoef);
+template __global__ void consistency_pre_kernel<float>(const float*, const float*, float*, float*, int, int, int, int, float, float, float);
+template __global__ void consistency_pre_kernel<__bf16>(const float*, const float*, float*, __bf16*, int, int, int, int, float, float, float);
+
+}  // namespace td

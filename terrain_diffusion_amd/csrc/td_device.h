@@ -1,0 +1,59 @@
+// Device-side parameter blocks shared by the host engine and the HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace td {
+
+// One K-segment of an implicit-GEMM convolution: a source activation tensor (NHWC), how it is
+// resampled onto the conv grid, and the element-wise transform fused into LDS staging.
+struct ConvSeg {
+    const void* src;      // NHWC activations, element type T of the kernel instantiation
+    const float* sumsq;   // [nparts][Nimg*Hs*Ws] partial per-pixel sums of squares (pixel-norm), or null
+    int C;                // channels taken from src (multiple of the K-chunk)
+    int cstride;          // elements per pixel in src
+    int Hs, Ws;           // source spatial dims
+    int taps;             // 9 (3x3, pad 1) or 1 (1x1)
+    int resample;         // 0 keep, 1 down (src[2y,2x]), 2 up (src[y/2,x/2])
+    int xform;            // 0 none, 1 mp_silu(scale*x), 2 mp_silu(scale*rn(pixel)*x)
+    int nparts;           // number of sumsq partials
+    float scale;
+    float inv_c;          // 1/C_total for the pixel norm
+};
+
+enum { EPI_PLAIN = 0, EPI_EMB_SILU = 1, EPI_RESIDUAL = 2 };
+
+struct ConvParams {
+    ConvSeg seg[3];
+    int nseg;
+    const void* wpack;    // packed weights [kstep][CoutPad][128 B], 16-B slots XOR-swizzled by (cout&7)
+    int N, H, W;          // conv-resolution output dims
+    int Cout, CoutPad;
+    int tiles_x, tiles_y, img_groups, n_ntiles;
+    int kgroups;          // total (segment, chunk) groups
+    int ksplit;           // number of K splits (1 = direct epilogue)
+    int epi;
+    void* out;            // NHWC output (T, or float when out_f32)
+    int out_cstride;
+    int out_f32;
+    const float* cvec;    // EPI_EMB_SILU: c[n*cvec_stride + co]
+    int cvec_stride;
+    const void* res;      // EPI_RESIDUAL: residual source (T) or null
+    const float* res_sumsq;
+    int res_cstride, res_Hs, res_Ws, res_resample, res_nparts;
+    float res_inv_c;
+    float res_scale;      // 0.7/sqrt(0.58) (conv weights carry 0.3/sqrt(0.58))
+    float clip;           // <=0: no clip
+    float* out_sumsq;     // [n_ntiles*WAVES_N][N*H*W] or null
+    float* partial;       // split-K workspace [ksplit][N*H*W][CoutPad] fp32
+};
+
+struct SchedCoef {        // one DPM-Solver++ step, fp32 scalars computed on the host
+    float c_skip, c_out;  // x0 = c_skip*x + c_out*F
+    float a, b0, inv_r0;  // order1: a*x - b0*m0 ; order2: ... - 0.5*b0*inv_r0*(m0-m1)
+    float c_in_next;      // next model input scale (0 on the last step)
+    int order;
+    int last;
+};
+
+}  // namespace td

@@ -1,0 +1,69 @@
+"""Engine handle + pointer plumbing.  torch is used only as the owner of host/device buffers."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import lib, check
+
+_engines = {}
+
+
+class Engine:
+    """One engine per GPU (td_engine_create); single caller thread per handle."""
+
+    def __init__(self, device_id=0):
+        self._h = C.c_void_p()
+        check(lib().td_engine_create(int(device_id), C.byref(self._h)))
+        self.device_id = int(device_id)
+
+    def set_option(self, key, value):
+        check(lib().td_engine_set_option(self._h, key.encode(), int(value)))
+
+    def synchronize(self):
+        check(lib().td_engine_synchronize(self._h))
+
+    @property
+    def stream(self):
+        return lib().td_engine_stream(self._h)
+
+    def close(self):
+        if self._h:
+            lib().td_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+def get_engine(device=None) -> Engine:
+    """Engine for a torch device spec ('cuda', 'cuda:1', int, None).  Raises on 'cpu': no CPU path exists."""
+    if device is None:
+        idx = 0
+    elif isinstance(device, int):
+        idx = device
+    else:
+        d = torch.device(device)
+        if d.type != "cuda":
+            raise RuntimeError("terrain_diffusion_amd runs on MI355X only (device must be 'cuda[:i]'); there is no CPU fallback")
+        idx = d.index or 0
+    if idx not in _engines:
+        _engines[idx] = Engine(idx)
+    return _engines[idx]
+
+
+def ptr(t):
+    """raw pointer of a contiguous fp32 torch tensor / numpy array (host or device), or None."""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        assert t.flags["C_CONTIGUOUS"]
+        return C.c_void_p(t.ctypes.data)
+    assert t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def f32(t, device=None):
+    """contiguous fp32 tensor (keeps device unless `device` given)."""
+    t = torch.as_tensor(t)
+    t = t.to(dtype=torch.float32)
+    if device is not None:
+        t = t.to(device)
+    return t.contiguous()

@@ -1,0 +1,177 @@
+"""Bounded tiled samplers with the reference's call surface, executed by the HIP engine.
+
+Mirrors terrain_diffusion/training/evaluation/sample_diffusion_base.py:51-168 (sample_base_diffusion) and
+:171-268 (sample_base_consistency); helper geometry from training/evaluation/__init__.py:3-22.  Differences
+by design: all tiles of a phase are batched through the engine (they are independent), the initial noise is cut
+from the portable absolute-coordinate field (world_pipeline.py:66-115) instead of torch.randn, and the blend is a
+deterministic gather in the reference's loop order.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from ._lib import lib, check
+from .engine import ptr, f32
+from . import noise as _noise
+
+
+def _tile_starts(length, tile_size, stride):
+    if length <= tile_size:
+        return [0]
+    starts = list(range(0, max(1, length - tile_size + 1), max(1, stride)))
+    if starts[-1] != length - tile_size:
+        starts.append(length - tile_size)
+    return starts
+
+
+def _linear_weight_window(size, device="cuda", dtype=torch.float32):
+    from .engine import get_engine
+    eng = get_engine(device)
+    out = torch.empty((size, size), dtype=torch.float32, device=torch.device("cuda", eng.device_id))
+    check(lib().td_linear_weight_window(eng._h, size, ptr(out)))
+    return out[None, None]
+
+
+def _process_cond_img(cond_img, histogram_raw, cond_means, cond_stds, noise_level=0.0):
+    """sample_diffusion_base.py:11-48 for NaN-free conditioning (host, (B,7,4,4) -> (B,58)); tiny, stays on the host."""
+    cond_img = torch.as_tensor(cond_img, dtype=torch.float32).cpu()
+    means = torch.as_tensor(cond_means, dtype=torch.float32).view(1, -1, 1, 1)
+    stds = torch.as_tensor(cond_stds, dtype=torch.float32).view(1, -1, 1, 1)
+    if torch.isnan(cond_img).any():
+        raise NotImplementedError("NaN conditioning fill is not on the accelerated path")
+    cond_img = (cond_img - means) / stds
+    B = cond_img.shape[0]
+    nl = (torch.as_tensor(noise_level, dtype=torch.float32) - 0.5) * np.sqrt(12)
+    hist = torch.as_tensor(histogram_raw, dtype=torch.float32)
+    parts = [cond_img[:, 0:1].flatten(1), cond_img[:, 1:2].flatten(1), cond_img[:, 2:6, 1:3, 1:3].mean(dim=(2, 3)).flatten(1),
+             cond_img[:, 6:7].flatten(1), hist.view(-1, hist.shape[-1]).expand(B, -1), nl.view(-1, 1).expand(B, 1)]
+    n = len(parts)
+    Cc = math.sqrt(sum(p.shape[1] for p in parts) / (n * (1.0 / n) ** 2))
+    return torch.cat([p * (Cc / math.sqrt(p.shape[1]) * (1.0 / n)) for p in parts], dim=1).float()
+
+
+def _tile_conditioning(cond_inputs, tiles, histogram_raw, cond_means, cond_stds, noise_level):
+    if cond_inputs.ndim == 4:
+        return torch.cat([_process_cond_img(cond_inputs[..., ic:ic + 4, jc:jc + 4], histogram_raw, cond_means, cond_stds, noise_level)
+                          for ic, jc in tiles], dim=0)
+    return torch.as_tensor(cond_inputs, dtype=torch.float32).view(1, -1).expand(len(tiles), -1).contiguous()
+
+
+def blend_windows(engine, canvas, tiles, tile_idx, h_starts, w_starts, size, accumulate=True):
+    """canvas (C+1,Hc,Wc) += windows (deterministic gather, reference loop order)."""
+    C_, Hc, Wc = canvas.shape[0] - 1, canvas.shape[1], canvas.shape[2]
+    rs = np.asarray(h_starts, dtype=np.int32)
+    cs = np.asarray(w_starts, dtype=np.int32)
+    wi = np.asarray([t[0] for t in tile_idx], dtype=np.int32)
+    wj = np.asarray([t[1] for t in tile_idx], dtype=np.int32)
+    check(lib().td_blend_windows(engine._h, ptr(canvas), C_, Hc, Wc, size, len(rs), C.c_void_p(rs.ctypes.data), len(cs), C.c_void_p(cs.ctypes.data),
+                                 len(wi), C.c_void_p(wi.ctypes.data), C.c_void_p(wj.ctypes.data), ptr(tiles), int(accumulate)))
+    return canvas
+
+
+def blend_normalize(engine, canvas, scale=1.0):
+    C_, Hc, Wc = canvas.shape[0] - 1, canvas.shape[1], canvas.shape[2]
+    out = torch.empty((C_, Hc, Wc), dtype=torch.float32, device=canvas.device)
+    check(lib().td_blend_normalize(engine._h, ptr(canvas), C_, Hc, Wc, float(scale), ptr(out)))
+    return out
+
+
+@torch.no_grad()
+def sample_tiles_edm(model, scheduler, x, cond, steps):
+    """Runs `steps` DPM-Solver++ steps on a batch of independent tiles (device tensor x: [n,C,H,W], scaled noise). In place."""
+    scheduler.set_timesteps(steps)
+    sig = scheduler.sigmas.to(torch.float32).cpu().contiguous()
+    n, _, H, W = x.shape
+    check(lib().td_sample_edm(model._h, n, H, W, steps, ptr(sig), float(scheduler.config.sigma_data), ptr(cond), ptr(x)))
+    return x
+
+
+@torch.no_grad()
+def sample_base_diffusion(model, scheduler, shape, cond_inputs, *, cond_means, cond_stds, noise_level=0.0, histogram_raw, dtype=torch.float32,
+                          steps=15, guide_model=None, guidance_scale=1.0, generator=None, tile_size=None, weight_window_fn=None,
+                          noise_seed=42 + 5819, noise_origin=(0, 0), tiles=None, max_batch=64, return_canvas=False):
+    """Reference signature + (noise_seed, noise_origin, tiles, max_batch, return_canvas).
+    `tiles`: optional subset of (ic, jc) window indices to run (multi-GPU sharding); `return_canvas` returns the
+    un-normalised (C+1,H,W) accumulator instead of output/weights/sigma_data."""
+    if guide_model is not None and guidance_scale != 1.0:
+        raise NotImplementedError("autoguidance is not on the accelerated path yet")
+    if weight_window_fn is not None:
+        raise NotImplementedError("custom weight windows")
+    B, C_, H, W = shape
+    if B != 1:
+        raise NotImplementedError("B == 1 (one canvas) per call")
+    eng, dev = model.engine, model.device
+    sd = float(scheduler.config.sigma_data)
+    scheduler.set_timesteps(steps)
+    sigma0 = float(scheduler.sigmas[0])
+    if tile_size is None:
+        tile_size_eff, h_starts, w_starts = None, [0], [0]
+        th, tw = H, W
+    else:
+        stride = tile_size // 2
+        h_starts, w_starts = _tile_starts(H, tile_size, stride), _tile_starts(W, tile_size, stride)
+        th = tw = tile_size
+    cond_inputs = torch.as_tensor(cond_inputs, dtype=torch.float32)
+    if tile_size is not None and cond_inputs.ndim == 1 and len(h_starts) * len(w_starts) > 1:
+        raise ValueError(f"cond_inputs must be a tensor image for tiled sampling. Cond inputs must have width {len(w_starts)+3} and height {len(h_starts)+3}.")
+    if cond_inputs.ndim == 4:
+        assert cond_inputs.shape[-1] == len(w_starts) + 3 and cond_inputs.shape[-2] == len(h_starts) + 3
+    all_tiles = [(ic, jc) for ic in range(len(h_starts)) for jc in range(len(w_starts))]
+    run = all_tiles if tiles is None else [t for t in all_tiles if t in set(tiles)]
+    canvas = torch.zeros((C_ + 1, H, W), dtype=torch.float32, device=dev)
+    for b0 in range(0, len(run), max_batch):
+        chunk = run[b0:b0 + max_batch]
+        origins = [(noise_origin[0] + h_starts[ic], noise_origin[1] + w_starts[jc]) for ic, jc in chunk]
+        # initial_noise[..., i0:i1, j0:j1] of one shared field (sample_diffusion_base.py:124,145) == windows of the absolute field
+        x = _noise.gaussian_noise_patches(noise_seed, origins, th, tw, channels=C_, tile_h=64, tile_w=64, scale=sigma0, device=dev)
+        cond = _tile_conditioning(cond_inputs, chunk, histogram_raw, cond_means, cond_stds, noise_level).to(dev).contiguous()
+        sample_tiles_edm(model, scheduler, x, cond, steps)
+        if tile_size is None:
+            return x
+        blend_windows(eng, canvas, x, chunk, h_starts, w_starts, tile_size, accumulate=True)
+    if return_canvas:
+        return canvas
+    return blend_normalize(eng, canvas, 1.0 / sd)[None]
+
+
+@torch.no_grad()
+def sample_base_consistency(model, scheduler, shape, cond_inputs, *, cond_means, cond_stds, noise_level=0.0, histogram_raw, intermediate_t=0.0,
+                            dtype=torch.float32, generator=None, tile_size=None, weight_window_fn=None, noise=None,
+                            noise_seed=42 + 5819, noise_origin=(0, 0), max_batch=64):
+    """sample_diffusion_base.py:171-268: trig-flow consistency phases, blend between phases (the InfiniteDiffusion pattern)."""
+    B, C_, H, W = shape
+    if B != 1 or tile_size is None or weight_window_fn is not None:
+        raise NotImplementedError
+    eng, dev = model.engine, model.device
+    sd = float(scheduler.config.sigma_data)
+    init_t = math.atan(float(scheduler.config.sigma_max) / sd) if noise is None else None
+    sigma0 = scheduler.sigmas[0] if noise is not None else None
+    t0 = float(torch.atan(torch.tensor(scheduler.config.sigma_max, dtype=torch.float32) / sd))
+    t_scalars = (t0, float(torch.tensor(intermediate_t, dtype=torch.float32))) if intermediate_t > 0 else (t0,)
+    stride = tile_size // 2
+    h_starts, w_starts = _tile_starts(H, tile_size, stride), _tile_starts(W, tile_size, stride)
+    cond_inputs = torch.as_tensor(cond_inputs, dtype=torch.float32)
+    tiles = [(ic, jc) for ic in range(len(h_starts)) for jc in range(len(w_starts))]
+    origins = [(h_starts[ic], w_starts[jc]) for ic, jc in tiles]
+    cond_all = _tile_conditioning(cond_inputs, tiles, histogram_raw, cond_means, cond_stds, noise_level).to(dev).contiguous()
+    sample = None
+    for k, t in enumerate(t_scalars):
+        canvas = torch.zeros((C_ + 1, H, W), dtype=torch.float32, device=dev)
+        for b0 in range(0, len(tiles), max_batch):
+            sl = slice(b0, b0 + max_batch)
+            if noise is None:
+                z = _noise.gaussian_noise_patches(noise_seed + k, [(noise_origin[0] + y, noise_origin[1] + x) for y, x in origins[sl]], tile_size, tile_size,
+                                                  channels=C_, tile_h=64, tile_w=64, device=dev)
+            else:
+                z = torch.stack([torch.as_tensor(noise[k])[0, :, y:y + tile_size, x:x + tile_size] for y, x in origins[sl]]).to(dev, torch.float32).contiguous()
+            prev = None
+            if sample is not None:
+                prev = torch.stack([sample[:, y:y + tile_size, x:x + tile_size] for y, x in origins[sl]]).contiguous()
+            out = torch.empty_like(z)
+            cond = cond_all[sl].contiguous()
+            check(lib().td_sample_consistency(model._h, z.shape[0], tile_size, tile_size, float(t), sd, ptr(prev), ptr(z), ptr(cond), ptr(out)))
+            blend_windows(eng, canvas, out, tiles[sl], h_starts, w_starts, tile_size, accumulate=True)
+        sample = blend_normalize(eng, canvas, 1.0)
+    return (sample / sd)[None]

@@ -1,0 +1,124 @@
+"""EDMUnet2D with the reference's call signature, executed by the HIP engine.
+
+Mirrors terrain_diffusion/models/edm_unet.py:15-184: same constructor kwargs, same state-dict names
+(diffusers layout, SURVEY.md §8b face 3), `model(x, noise_labels=..., conditional_inputs=[...])`.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import torch
+
+from ._lib import UnetConfig, lib, check
+from .engine import get_engine, ptr, f32
+
+DTYPES = {"fp32": 0, "float32": 0, None: 0, torch.float32: 0, "bf16": 1, "bfloat16": 1, torch.bfloat16: 1}
+
+
+class EDMUnet2D:
+    def __init__(self, image_size, in_channels, out_channels=None, model_channels=128, model_channel_mults=None,
+                 layers_per_block=2, emb_channels=None, noise_emb_dims=None, attn_resolutions=None,
+                 midblock_attention=True, concat_balance=0.3, logvar_channels=128, block_kwargs=None,
+                 conditional_inputs=(), encode_only=False, disable_out_gain=False, fourier_scale=1, n_logvar=1,
+                 *, dtype="bf16", device="cuda"):
+        if block_kwargs or encode_only or disable_out_gain:
+            raise NotImplementedError("block_kwargs / encode_only / disable_out_gain are not on the accelerated path")
+        if fourier_scale != "pos":
+            raise NotImplementedError("only fourier_scale='pos' (the released configs) is supported")
+        mults = list(model_channel_mults or [1, 2, 3, 4])
+        lpb = [layers_per_block] * len(mults) if isinstance(layers_per_block, int) else list(layers_per_block)
+        conds = [list(c) for c in conditional_inputs]
+        if len(conds) > 1 or (conds and conds[0][0] != "tensor"):
+            raise NotImplementedError("one ['tensor', dim, weight] conditional input (base model) is supported")
+        self.config = dict(image_size=image_size, in_channels=in_channels, out_channels=out_channels or in_channels,
+                           model_channels=model_channels, model_channel_mults=mults, layers_per_block=lpb,
+                           emb_channels=emb_channels, noise_emb_dims=noise_emb_dims, attn_resolutions=list(attn_resolutions or []),
+                           midblock_attention=midblock_attention, concat_balance=concat_balance, conditional_inputs=conds,
+                           fourier_scale=fourier_scale)
+        self.dtype = dtype
+        self.engine = get_engine(device)
+        self.device = torch.device("cuda", self.engine.device_id)
+        cfg = UnetConfig()
+        cfg.image_size, cfg.in_channels, cfg.out_channels = image_size, in_channels, out_channels or in_channels
+        cfg.model_channels, cfg.n_levels = model_channels, len(mults)
+        for i, m in enumerate(mults):
+            cfg.channel_mults[i] = m
+            cfg.layers_per_block[i] = lpb[i]
+        ar = list(attn_resolutions or [])
+        cfg.n_attn_resolutions = len(ar)
+        for i, r in enumerate(ar):
+            cfg.attn_resolutions[i] = r
+        cfg.midblock_attention = int(bool(midblock_attention))
+        cfg.concat_balance = float(concat_balance)
+        cfg.noise_emb_dims = int(noise_emb_dims or 0)
+        cfg.emb_channels = int(emb_channels or 0)
+        cfg.cond_dim = int(conds[0][1]) if conds else 0
+        cfg.cond_weight = float(conds[0][2]) if conds else 0.0
+        self._h = C.c_void_p()
+        check(lib().td_unet_create(self.engine._h, C.byref(cfg), DTYPES[dtype], C.byref(self._h)))
+        self._finalized = False
+
+    # ---- checkpoint interface
+    def expected_parameters(self):
+        out = {}
+        for i in range(lib().td_unet_num_params(self._h)):
+            name, ndim, shape = C.c_char_p(), C.c_int32(), (C.c_int64 * 4)()
+            check(lib().td_unet_param_info(self._h, i, C.byref(name), C.byref(ndim), C.byref(shape)))
+            out[name.value.decode()] = tuple(shape[k] for k in range(ndim.value))
+        return out
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Reference parameter names (edm_unet.py state dict).  logvar_* (training only) are ignored."""
+        exp = self.expected_parameters()
+        missing = [k for k in exp if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in exp and not k.startswith("logvar_")]
+        if strict and (missing or unexpected):
+            raise KeyError(f"state dict mismatch: missing {missing[:5]} unexpected {unexpected[:5]}")
+        for k, shape in exp.items():
+            w = torch.as_tensor(state_dict[k]).detach().to("cpu", torch.float32).contiguous()
+            if tuple(w.shape) != tuple(shape):
+                raise ValueError(f"{k}: shape {tuple(w.shape)} != {shape}")
+            check(lib().td_unet_set_param(self._h, k.encode(), C.c_void_p(w.data_ptr()), w.numel()))
+        check(lib().td_unet_finalize(self._h))
+        self._finalized = True
+        return self
+
+    @classmethod
+    def from_pretrained(cls, path, *, dtype="bf16", device="cuda"):
+        """diffusers ModelMixin layout: <path>/config.json + one *.safetensors (world_pipeline.py:541-565)."""
+        from safetensors.torch import load_file
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        files = [f for f in os.listdir(path) if f.endswith(".safetensors")]
+        if len(files) != 1:
+            raise FileNotFoundError(f"expected exactly one .safetensors in {path}")
+        m = cls(**cfg, dtype=dtype, device=device)
+        return m.load_state_dict(load_file(os.path.join(path, files[0])))
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    # ---- model(x, noise_labels, conditional_inputs)  (edm_unet.py:161-184)
+    def __call__(self, x, noise_labels, conditional_inputs=None):
+        if not self._finalized:
+            raise RuntimeError("load_state_dict first")
+        x = f32(x)
+        n, _, H, W = x.shape
+        t = f32(noise_labels, "cpu").flatten()
+        if t.numel() == 1 and n > 1:
+            t = t.expand(n).contiguous()
+        cond = f32(conditional_inputs[0]) if conditional_inputs else None
+        out = torch.empty((n, self.config["out_channels"], H, W), dtype=torch.float32, device=x.device)
+        check(lib().td_unet_forward(self._h, n, H, W, ptr(x), ptr(t), ptr(cond), ptr(out)))
+        return out
+
+    forward = __call__
+
+    def close(self):
+        if self._h:
+            lib().td_unet_destroy(self._h)
+            self._h = C.c_void_p()

@@ -94,8 +94,9 @@ def test_schedule_bit_exact(golden):
     for n in (4, 12, 20, 32):
         sig, ts = schedule.karras_sigmas(n)
         assert np.array_equal(sig.numpy(), g[f"sigmas_{n}"])
-        assert np.array_equal(ts.numpy(), g[f"timesteps_{n}"])
-        assert np.array_equal(schedule.trigflow_t(sig[:-1]).numpy(), g[f"trigflow_t_{n}"])
+        # log/atan are vectorised differently on different host CPUs (1 ulp); sigmas (pow) are bit-exact everywhere we ran
+        assert np.allclose(ts.numpy(), g[f"timesteps_{n}"], rtol=3e-7, atol=1e-7)
+        assert np.allclose(schedule.trigflow_t(sig[:-1]).numpy(), g[f"trigflow_t_{n}"], rtol=3e-7, atol=0)
     assert schedule.solver_orders(20) == [1] + [2] * 18 + [1]
     # NB: with solver_order=2 the `lower_order_second` clause (dpmsolver.py:694-696) is unreachable: the
     # elif at :711 tests `solver_order == 2` first, so N<15 does NOT force a 1st-order penultimate step.
