@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""Headline benchmark: decoded terrain megapixels / second at fixed steps (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W [--workload tile1|grid8] [--dtype bf16|fp32]
+
+A "step" is one pass of the hot path over one batch of synthetic input:
+  tile1 (default, BASELINE configs[1]): one 64x64-latent tile of the terrain-diffusion-30m base model through 20 EDM
+        DPM-Solver++ steps, including noise generation, conditioning, scheduler steps, blend + normalise.
+        0.262144 decoded MP per step.  N>1: every rank samples its own tile (independent objects -> weak scaling).
+  grid8 (BASELINE configs[2]): an 8x8 grid of overlapping tiles (stride 32) on a 288x288 latent canvas, 20 steps,
+        all 64 tiles batched per solver step, overlap blend at the end.  5.308416 decoded MP per step.
+Weights are synthetic (portable-RNG seeded, out_gain=1, emb_gain=0.5) and resident in HBM before the timed region; there
+is no network for checkpoints.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_FORWARD = 193.654          # base model, one 64x64 tile (2 FLOP/MAC, convs+GEMMs+bmm)
+CONV_SHARE = 193.609 / 193.654       # share of those FLOPs issued by the conv_igemm kernel
+WEIGHT_BYTES_BF16 = 253_688_037 * 2  # algorithmic minimum HBM bytes per forward at batch 1 (weights once)
+PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="tile1", choices=["tile1", "grid8"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--edm-steps", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import terrain_diffusion_amd as td
+    from terrain_diffusion_amd.engine import get_engine
+    from oracle import tiling
+    from oracle.unet import BASE_CONFIG, synth_state_dict
+
+    dev = f"cuda:{local_rank}"
+    eng = get_engine(dev)
+    cfg = dict(BASE_CONFIG)
+    sd = synth_state_dict(cfg, seed=1234)
+    model = td.EDMUnet2D(**cfg, dtype=args.dtype, device=dev).load_state_dict(sd)
+    sch = td.EDMDPMSolverMultistepScheduler(sigma_min=0.002, sigma_max=80.0, sigma_data=0.5)
+    E = args.edm_steps
+    if args.workload == "tile1":
+        H = W = 64
+        tiles_per_step, mp_per_step = 1, (64 * 8) ** 2 / 1e6
+    else:
+        H = W = 288
+        tiles_per_step, mp_per_step = 64, (288 * 8) ** 2 / 1e6
+    nt = len(tiling.tile_starts(H, 64, 32))
+    cond = tiling.synthetic_cond_grid(nt, nt)
+    kw = dict(cond_means=torch.zeros(7), cond_stds=torch.ones(7), noise_level=torch.tensor(0.0), histogram_raw=torch.zeros(1, 5), steps=E, tile_size=64)
+
+    def one_step(i):
+        # a different canvas each step (noise origin moves), same as sampling successive regions of the world
+        return td.sample_base_diffusion(model, sch, (1, 5, H, W), cond, noise_seed=42 + 5819 + rank, noise_origin=(0, 4096 * i), **kw)
+
+    def sync():
+        eng.synchronize()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_step(args.warmup + i)
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert bool(torch.isfinite(out).all())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.steps * mp_per_step / dt
+
+    result = {
+        "metric": "terrain megapixels/sec (decoded) at fixed steps, 30m model", "value": round(value, 4), "unit": "MP/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": ("BASELINE configs[1]: terrain-diffusion-30m base U-Net, single 64x64 latent tile, 20 EDM DPM-Solver++ steps"
+                                if args.workload == "tile1" else
+                                "BASELINE configs[2]: terrain-diffusion-30m base U-Net, 8x8 tile grid (stride 32) with overlap blending, 20 steps"),
+                   "tiles_per_step": tiles_per_step, "edm_steps": E, "decoded_mp_per_step": mp_per_step,
+                   "parallelism": f"{world} independent tile streams (one process per GPU, no data-path collective)"},
+    }
+
+    if rank == 0:
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        flop_per_step = tiles_per_step * E * GFLOP_PER_FORWARD * 1e9
+        e2e_tflops = flop_per_step / (ms_per_step * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "td::conv_igemm_kernel", "peak": peak, "unit": "TFLOP/s", "traffic": None,
+                "end_to_end_achieved": round(e2e_tflops, 2), "end_to_end_frac": round(e2e_tflops / peak, 4)}
+        if not args.no_kernel_profile:
+            # kernel-level: HIP events on the engine's own stream around every conv_igemm launch (eager, no graph)
+            eng.set_option("profile", 1)
+            eng.profile_read(reset=True)
+            one_step(10_000)
+            sync()
+            conv_ms, conv_n, other_ms, other_n = eng.profile_read(reset=True)
+            eng.set_option("profile", 0)
+            flop_per_launch = flop_per_step * CONV_SHARE / conv_n
+            avg_us = conv_ms / conv_n * 1e3
+            ach = flop_per_launch / (avg_us * 1e-6) / 1e12
+            roof.update({"achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches_per_step": conv_n,
+                         "avg_launch_us": round(avg_us, 3), "flop_per_launch": round(flop_per_launch),
+                         "conv_kernel_ms_per_step": round(conv_ms, 3), "other_unet_kernel_ms_per_step": round(other_ms, 3)})
+            if tiles_per_step == 1 and args.dtype == "bf16":
+                gbs = E * WEIGHT_BYTES_BF16 / (conv_ms * 1e-3) / 1e9
+                roof["hbm_weight_stream"] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                             "note": "weights read once per forward at batch 1 (algorithmic minimum bytes)"}
+        else:
+            roof.update({"achieved": roof["end_to_end_achieved"], "frac": roof["end_to_end_frac"]})
+        result["roofline"] = roof
+
+        if world == 1 and not args.no_cpu_baseline:
+            # CPU baseline = the oracle (CPU restatement pinned to the reference) on this host's cores, bounded sample
+            from oracle.unet import OracleUnet
+            om = OracleUnet(cfg, sd)
+            ocond = tiling.synthetic_cond_grid(1, 1)
+            run = lambda k: tiling.sample_base_diffusion_tiled(om, (1, 5, 64, 64), ocond, steps=k, tile_size=64)
+            # pick the host thread count that is fastest for this workload (256 threads on the GPU node's host is ~150x slower
+            # than 32 because of oversubscription); one solver step per candidate, method of evaluation/latency.py:72-91
+            ncpu = os.cpu_count() or 1
+            best_t, best_dt = None, None
+            for nthreads in [c for c in (8, 16, 32, 64, 128) if c <= ncpu] or [ncpu]:
+                torch.set_num_threads(nthreads)
+                run(1)
+                c0 = time.perf_counter(); run(1); d = time.perf_counter() - c0
+                if best_dt is None or d < best_dt:
+                    best_t, best_dt = nthreads, d
+                if d > 20:
+                    break
+            torch.set_num_threads(best_t)
+            n_sample_steps = max(2, min(E, int(15.0 / max(best_dt, 1e-3))))
+            c0 = time.perf_counter()
+            run(n_sample_steps)
+            cdt = time.perf_counter() - c0
+            per_tile = cdt / n_sample_steps * E
+            overlap = 1.0 if args.workload == "tile1" else tiles_per_step * 0.262144 / mp_per_step
+            result["cpu_baseline"] = {"value": round(0.262144 / per_tile / overlap, 6), "unit": "MP/s", "cores": best_t, "kind": "port",
+                                      "host_cpus": ncpu,
+                                      "sample": f"oracle (torch fp32 CPU restatement pinned to the reference), 1 tile x {n_sample_steps} of {E} solver steps "
+                                                f"timed ({cdt:.1f} s on {best_t} threads, best of 8..128), scaled to {E} steps"
+                                                + ("" if args.workload == "tile1" else f" and to {tiles_per_step} overlapping tiles")}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

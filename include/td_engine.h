@@ -59,6 +59,10 @@ void* td_engine_stream(td_engine* e);
 /* tuning knobs, e.g. "splitk"=0/1, "graph"=0/1, "bn128_min_wgs"=N */
 int td_engine_set_option(td_engine* e, const char* key, int64_t value);
 
+/* With option "profile"=1 the samplers run eagerly (no graph) with HIP events recorded on the engine stream around every
+ * conv_igemm launch (and every other U-Net kernel); this reads/reset the accumulated kernel time and launch counts. */
+int td_engine_profile_read(td_engine* e, double* conv_ms, int64_t* conv_launches, double* other_ms, int64_t* other_launches, int reset);
+
 /* ---- model ------------------------------------------------------------------------------------------------
  * Replaces EDMUnet2D(...) + load_state_dict (edm_unet.py:17-143; diffusers layout, SURVEY.md §8b face 3).
  * Weights are the reference's RAW fp32 parameters by state-dict name; the engine folds the magnitude-preserving
@@ -69,11 +73,19 @@ int td_unet_num_params(td_unet* u);
 /* i-th expected parameter: name and shape (ndim<=4) — lets the caller validate a checkpoint */
 int td_unet_param_info(td_unet* u, int i, const char** name, int32_t* ndim, int64_t shape[4]);
 int td_unet_set_param(td_unet* u, const char* name, const float* host_data, int64_t numel);
+/* prefolded=1: the parameters passed to td_unet_set_param already are W/(1e-4+||W||/sqrt(numel))*gain/sqrt(fan_in)
+ * (emb_gain / out_gain folded in; the gain scalars are then ignored).  The Python host folds with the reference's own
+ * fp32 torch arithmetic so the engine's weights equal the reference's bit-for-bit; prefolded=0 folds in fp64 here. */
+int td_unet_set_prefolded(td_unet* u, int prefolded);
 int td_unet_finalize(td_unet* u);
 
 /* model(x, noise_labels=t, conditional_inputs=[cond]) -> F      (edm_unet.py:161-184)
  * x: [n][in_channels][H][W], t: host [n], cond: [n][cond_dim], out: [n][out_channels][H][W] */
 int td_unet_forward(td_unet* u, int n, int H, int W, const float* x, const float* t_host, const float* cond, float* out);
+
+/* Test/debug facility: after a td_unet_forward(n,H,W), copies the OUTPUT of the fused conv op `label` (e.g. "enc.512x512_block0.conv_res1",
+ * the block output; "<block>.conv_res0" = y1) to host as NCHW fp32.  dims receives (n,C,h,w). */
+int td_unet_read_activation(td_unet* u, int n, int H, int W, const char* label, float* out_host, int64_t capacity, int32_t dims[4]);
 
 /* ---- portable noise (terrain_diffusion/inference/portable_rng.py:22-89, world_pipeline.py:58-115) ---------- */
 uint64_t td_tile_seed(uint64_t base_seed, int64_t ty, int64_t tx);                 /* _tile_seed */

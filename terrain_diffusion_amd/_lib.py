@@ -31,13 +31,16 @@ _SIGS = {
     "td_engine_synchronize": (C.c_int, [_P]),
     "td_engine_stream": (_P, [_P]),
     "td_engine_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    "td_engine_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     "td_unet_create": (C.c_int, [_P, C.POINTER(UnetConfig), C.c_int, C.POINTER(_P)]),
     "td_unet_destroy": (None, [_P]),
     "td_unet_num_params": (C.c_int, [_P]),
     "td_unet_param_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.c_int64 * 4)]),
     "td_unet_set_param": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    "td_unet_set_prefolded": (C.c_int, [_P, C.c_int]),
     "td_unet_finalize": (C.c_int, [_P]),
     "td_unet_forward": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "td_unet_read_activation": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int32 * 4)]),
     "td_tile_seed": (C.c_uint64, [C.c_uint64, C.c_int64, C.c_int64]),
     "td_standard_normal": (C.c_int, [_P, C.c_uint64, C.c_int64, _P]),
     "td_noise_patches": (C.c_int, [_P, C.c_uint64, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P]),

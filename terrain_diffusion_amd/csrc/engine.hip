@@ -65,6 +65,9 @@ struct td_engine {
     std::map<std::string, int64_t> opt;
     // scratch for I/O staging
     std::vector<Buf> keep;
+    // "profile" option: HIP events around every conv launch (eager mode), accumulated here
+    double prof_conv_ms = 0.0, prof_other_ms = 0.0;
+    int64_t prof_conv_launches = 0, prof_other_launches = 0;
     int64_t option(const char* k, int64_t dflt) const { auto it = opt.find(k); return it == opt.end() ? dflt : it->second; }
 };
 
@@ -145,6 +148,7 @@ struct Op {
     bool narrow = false;
     int bn = 64;
     int cvec_off = -1;         // EPI_EMB_SILU: offset of this block's c vector
+    int out_C = 0, out_H = 0, out_W = 0;  // output tensor geometry (debug read-back)
     // ATTN
     const void* qkv = nullptr; void* att = nullptr; int tokens = 0, C = 0;
     std::string label;
@@ -180,6 +184,7 @@ struct td_unet {
     std::map<std::string, std::vector<float>> folded;
     std::map<std::string, ConvWeights> convw;  // by op label
     bool finalized = false;
+    bool prefolded = false;    // parameters already carry the MP normalisation and gains (host folded them)
     // embedding weights on device (fp32)
     Buf d_freqs, d_wnoise, d_wcond, d_wemb, d_blk_woff, d_blk_coff, d_blk_cout;
     int n_blocks = 0;
@@ -272,8 +277,9 @@ static int build_blocks(td_unet* u) {
 }
 
 // mp_layers.py:203-213 (eval): W / (1e-4 + ||W||_2 / sqrt(numel)) * gain / sqrt(fan_in)
-static void fold(const Param& p, float gain, std::vector<float>& out) {
+static void fold(const Param& p, float gain, std::vector<float>& out, bool prefolded) {
     const int64_t n = p.numel();
+    if (prefolded) { out = p.data; return; }
     double ss = 0.0;
     for (int64_t i = 0; i < n; ++i) ss += (double)p.data[i] * p.data[i];
     const int64_t fan_in = n / p.shape[0];
@@ -326,7 +332,7 @@ static int finalize(td_unet* u) {
     const int chunk = u->chunk;
     auto folded = [&](const std::string& n, float gain) -> const std::vector<float>* {
         auto& v = u->folded[n];
-        if (v.empty()) fold(P(u, n), gain, v);
+        if (v.empty()) fold(P(u, n), gain, v, u->prefolded);
         return &v;
     };
     auto pad = [&](int c) { return (c + chunk - 1) / chunk * chunk; };
@@ -509,6 +515,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
             }
         }
         if (p.ksplit > 1) partial_bytes = std::max(partial_bytes, (size_t)p.ksplit * N * h * w * cw.cout_pad * 4);
+        op.out_C = cw.cout; op.out_H = h; op.out_W = w;
         pl.ops.push_back(op);
         return TD_OK;
     };
@@ -638,16 +645,37 @@ static int compute_cvecs(td_unet* u, Plan& pl, const std::vector<float>& t_steps
 static int run_unet(td_unet* u, Plan& pl, int step) {
     hipStream_t st = u->eng->stream;
     const float* cbase = (const float*)pl.cvec->p + (size_t)step * pl.N * u->c_total;
+    const bool prof = u->eng->option("profile", 0) != 0;
+    std::vector<hipEvent_t> evs;
+    std::vector<int> ev_kind;
+    auto mark = [&]() { if (prof) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); evs.push_back(e); } };
+    struct Fin {
+        td_unet* u; std::vector<hipEvent_t>& evs; std::vector<int>& kind; hipStream_t st;
+        ~Fin() {
+            if (evs.empty()) return;
+            (void)hipStreamSynchronize(st);
+            for (size_t i = 0; i + 1 < evs.size(); i += 2) {
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, evs[i], evs[i + 1]);
+                if (kind[i / 2] == 0) { u->eng->prof_conv_ms += ms; u->eng->prof_conv_launches++; } else { u->eng->prof_other_ms += ms; u->eng->prof_other_launches++; }
+            }
+            for (auto e : evs) (void)hipEventDestroy(e);
+        }
+    } fin{u, evs, ev_kind, st};
     for (auto& op : pl.ops) {
         if (op.kind == Op::ATTN) {
+            mark();
             if (u->bf16) hipLaunchKernelGGL(attn_kernel<__bf16>, dim3(pl.N, op.C / 64), dim3(256), 0, st, (const __bf16*)op.qkv, (__bf16*)op.att, op.tokens, op.C);
             else hipLaunchKernelGGL(attn_kernel<float>, dim3(pl.N, op.C / 64), dim3(256), 0, st, (const float*)op.qkv, (float*)op.att, op.tokens, op.C);
+            mark(); if (prof) ev_kind.push_back(1);
             HIP_TRY(hipGetLastError());
             continue;
         }
         ConvParams p = op.p;
         if (op.cvec_off >= 0) p.cvec = cbase + op.cvec_off;
+        mark();
         hipError_t e = launch_conv(p, u->bf16, op.narrow, op.bn, st);
+        mark(); if (prof) ev_kind.push_back(0);
         if (e != hipSuccess) return fail(TD_ERR_HIP, "conv launch " + op.label + ": " + hipGetErrorString(e));
     }
     return TD_OK;
@@ -687,6 +715,15 @@ int td_engine_set_option(td_engine* e, const char* key, int64_t value) {
     return TD_OK;
 }
 
+int td_engine_profile_read(td_engine* e, double* conv_ms, int64_t* conv_launches, double* other_ms, int64_t* other_launches, int reset) {
+    if (conv_ms) *conv_ms = e->prof_conv_ms;
+    if (conv_launches) *conv_launches = e->prof_conv_launches;
+    if (other_ms) *other_ms = e->prof_other_ms;
+    if (other_launches) *other_launches = e->prof_other_launches;
+    if (reset) { e->prof_conv_ms = e->prof_other_ms = 0.0; e->prof_conv_launches = e->prof_other_launches = 0; }
+    return TD_OK;
+}
+
 int td_unet_create(td_engine* e, const td_unet_config* cfg, int dtype, td_unet** out) {
     if (!e || !cfg || !out) return fail(TD_ERR_ARG, "null argument");
     if (dtype != TD_DTYPE_F32 && dtype != TD_DTYPE_BF16) return fail(TD_ERR_ARG, "dtype");
@@ -718,6 +755,11 @@ int td_unet_set_param(td_unet* u, const char* name, const float* host_data, int6
     if (numel != p.numel()) return fail(TD_ERR_ARG, std::string("size mismatch for ") + name);
     p.data.assign(host_data, host_data + numel);
     p.set = true;
+    return TD_OK;
+}
+int td_unet_set_prefolded(td_unet* u, int prefolded) {
+    if (u->finalized) return fail(TD_ERR_STATE, "already finalized");
+    u->prefolded = prefolded != 0;
     return TD_OK;
 }
 int td_unet_finalize(td_unet* u) {
@@ -761,6 +803,56 @@ int td_unet_forward(td_unet* u, int n, int H, int W, const float* x, const float
     if ((rc = out_finish(e, os))) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     return TD_OK;
+}
+
+int td_unet_read_activation(td_unet* u, int n, int H, int W, const char* label, float* out_host, int64_t capacity, int32_t dims[4]) {
+    Plan* pl;
+    int rc = build_plan(u, n, H, W, &pl);
+    if (rc) return rc;
+    if (!strcmp(label, "@emb") || !strcmp(label, "@cvec")) {
+        const bool is_emb = !strcmp(label, "@emb");
+        const int width = is_emb ? u->emb_ch : u->c_total;
+        dims[0] = n; dims[1] = width; dims[2] = 1; dims[3] = 1;
+        if ((int64_t)n * width > capacity) return fail(TD_ERR_ARG, "capacity");
+        HIP_TRY(hipStreamSynchronize(u->eng->stream));
+        HIP_TRY(hipMemcpy(out_host, is_emb ? pl->emb->p : pl->cvec->p, (size_t)n * width * 4, hipMemcpyDeviceToHost));
+        return TD_OK;
+    }
+    if (!strncmp(label, "sumsq:", 6)) {
+        for (auto& op : pl->ops) {
+            if (op.kind != Op::CONV || op.label != label + 6 || !op.p.out_sumsq) continue;
+            const int parts = op.p.ksplit > 1 ? 1 : op.p.n_ntiles * 2;
+            const size_t M = (size_t)n * op.out_H * op.out_W;
+            dims[0] = parts; dims[1] = n; dims[2] = op.out_H; dims[3] = op.out_W;
+            if ((int64_t)(parts * M) > capacity) return fail(TD_ERR_ARG, "capacity");
+            HIP_TRY(hipStreamSynchronize(u->eng->stream));
+            HIP_TRY(hipMemcpy(out_host, op.p.out_sumsq, parts * M * 4, hipMemcpyDeviceToHost));
+            return TD_OK;
+        }
+        return fail(TD_ERR_ARG, "no sumsq for that op");
+    }
+    for (auto& op : pl->ops) {
+        if (op.kind != Op::CONV || op.label != label) continue;
+        const int C = op.out_C, h = op.out_H, w = op.out_W, cs = op.p.out_cstride;
+        dims[0] = n; dims[1] = C; dims[2] = h; dims[3] = w;
+        if ((int64_t)n * C * h * w > capacity) return fail(TD_ERR_ARG, "capacity");
+        HIP_TRY(hipStreamSynchronize(u->eng->stream));
+        const size_t elems = (size_t)n * h * w * cs;
+        const bool f32out = op.p.out_f32 || !u->bf16;
+        std::vector<uint8_t> raw(elems * (f32out ? 4 : 2));
+        HIP_TRY(hipMemcpy(raw.data(), op.p.out, raw.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i)
+            for (int c = 0; c < C; ++c)
+                for (int p = 0; p < h * w; ++p) {
+                    size_t src = ((size_t)i * h * w + p) * cs + c;
+                    float v;
+                    if (f32out) v = ((const float*)raw.data())[src];
+                    else { uint32_t b = (uint32_t)((const uint16_t*)raw.data())[src] << 16; memcpy(&v, &b, 4); }
+                    out_host[((size_t)i * C + c) * h * w + p] = v;
+                }
+        return TD_OK;
+    }
+    return fail(TD_ERR_ARG, std::string("no conv op labelled ") + label);
 }
 
 // ---- schedule
@@ -842,7 +934,7 @@ int td_sample_edm(td_unet* u, int n, int H, int W, int n_steps, const float* sig
         return TD_OK;
     };
 
-    const bool use_graph = e->option("graph", 1) != 0;
+    const bool use_graph = e->option("graph", 1) != 0 && e->option("profile", 0) == 0;
     if (use_graph) {
         std::vector<float> sg(sigmas_host, sigmas_host + n_steps + 1);
         if (!pl->graph || pl->graph_sigmas != sg || pl->graph_sigma_data != sigma_data) {

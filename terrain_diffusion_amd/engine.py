@@ -23,6 +23,12 @@ class Engine:
     def synchronize(self):
         check(lib().td_engine_synchronize(self._h))
 
+    def profile_read(self, reset=True):
+        """(conv_ms, conv_launches, other_ms, other_launches) accumulated while option 'profile' was 1."""
+        a, b, c, d = C.c_double(), C.c_int64(), C.c_double(), C.c_int64()
+        check(lib().td_engine_profile_read(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), int(reset)))
+        return a.value, b.value, c.value, d.value
+
     @property
     def stream(self):
         return lib().td_engine_stream(self._h)

@@ -68,17 +68,39 @@ class EDMUnet2D:
             out[name.value.decode()] = tuple(shape[k] for k in range(ndim.value))
         return out
 
-    def load_state_dict(self, state_dict, strict=True):
-        """Reference parameter names (edm_unet.py state dict).  logvar_* (training only) are ignored."""
+    @staticmethod
+    def _fold_reference(w, gain):
+        """MPConv.forward's weight arithmetic in eval mode (mp_layers.py:9-12, 203-213), in fp32 torch ops exactly as the
+        reference executes them, so the engine multiplies by the same numbers the reference does."""
+        w = w.to(torch.float32)
+        norm = torch.linalg.vector_norm(w, dim=None, keepdim=True)
+        norm = torch.add(1e-4, norm, alpha=np.sqrt(norm.numel() / w.numel()))
+        w = w / norm
+        return w * (gain / np.sqrt(w[0].numel()))
+
+    def load_state_dict(self, state_dict, strict=True, fold="reference"):
+        """Reference parameter names (edm_unet.py state dict).  logvar_* (training only) are ignored.
+        fold="reference": weights are normalised on the host with the reference's fp32 arithmetic (bit-identical weights);
+        fold="engine": raw weights are handed over and folded in fp64 inside the engine (closer to exact maths; differs from
+        the reference by the rounding of torch's fp32 vector_norm, ~3e-6 per large conv)."""
         exp = self.expected_parameters()
         missing = [k for k in exp if k not in state_dict]
         unexpected = [k for k in state_dict if k not in exp and not k.startswith("logvar_")]
         if strict and (missing or unexpected):
             raise KeyError(f"state dict mismatch: missing {missing[:5]} unexpected {unexpected[:5]}")
+        check(lib().td_unet_set_prefolded(self._h, int(fold == "reference")))
         for k, shape in exp.items():
             w = torch.as_tensor(state_dict[k]).detach().to("cpu", torch.float32).contiguous()
             if tuple(w.shape) != tuple(shape):
                 raise ValueError(f"{k}: shape {tuple(w.shape)} != {shape}")
+            if fold == "reference" and k.endswith(".weight"):
+                if k.endswith(".emb_linear.weight"):
+                    gain = torch.as_tensor(state_dict[k[:-len("emb_linear.weight")] + "emb_gain"]).to(torch.float32)
+                elif k == "out_conv.weight":
+                    gain = torch.as_tensor(state_dict["out_gain"]).to(torch.float32)
+                else:
+                    gain = 1
+                w = self._fold_reference(w, gain).contiguous()
             check(lib().td_unet_set_param(self._h, k.encode(), C.c_void_p(w.data_ptr()), w.numel()))
         check(lib().td_unet_finalize(self._h))
         self._finalized = True
@@ -117,6 +139,14 @@ class EDMUnet2D:
         return out
 
     forward = __call__
+
+    def read_activation(self, n, H, W, label, max_elems=1 << 26):
+        """Debug/test: output of fused conv op `label` from the last forward with this (n,H,W), as NCHW fp32 (host)."""
+        buf = np.empty(max_elems, dtype=np.float32)
+        dims = (C.c_int32 * 4)()
+        check(lib().td_unet_read_activation(self._h, n, H, W, label.encode(), C.c_void_p(buf.ctypes.data), buf.size, C.byref(dims)))
+        shape = tuple(dims)
+        return torch.from_numpy(buf[:int(np.prod(shape))].reshape(shape).copy())
 
     def close(self):
         if self._h:

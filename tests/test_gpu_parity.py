@@ -3,9 +3,11 @@
 Tolerances (stated per SURVEY.md §8d):
   * integer work (tile seeds, PCG stream -> accept/reject order): bit-exact; normals: <= 1 ulp fp32 (f64 log on the
     device is not correctly rounded), with >= 99.99 % of values bit-identical.
-  * fp32 mode (exact-fp32 MFMA): <= 2e-5 rel-RMS per forward, <= 1e-4 after 20 solver steps.
-  * bf16 mode (bf16 storage, fp32 accumulate): <= 3e-2 rel-RMS per forward and after 20 steps
-    (reference's own bf16-vs-fp32: 1.0e-2 / 1.5e-2).
+  * fp32 mode (exact-fp32 MFMA, weights folded with the reference's fp32 arithmetic): <= 5e-6 rel-RMS per forward,
+    <= 1e-5 after 20 solver steps (measured 7.1e-7 / 3.8e-7 on the full-size base model; the reference's own
+    fp32-vs-fp64 is 4.7e-7 / 3.0e-7).
+  * bf16 mode (bf16 storage, fp32 accumulate): <= 2e-2 rel-RMS per forward and after 20 steps (measured 6.2e-3 / 4.0e-3;
+    the reference's own bf16-vs-fp32 is 1.0e-2 / 1.5e-2).
 """
 import numpy as np
 import pytest
@@ -103,7 +105,7 @@ def test_weight_window_exact(td, golden):
 
 
 # ------------------------------------------------------------------------------------------- U-Net forward
-@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 5e-6), ("bf16", 2e-2)])
 def test_unet_tiny(td, orc, golden, dtype, tol):
     g = golden("unet")
     cfg = orc["unet"].tiny_config(64, 1)
@@ -120,7 +122,7 @@ def test_unet_tiny(td, orc, golden, dtype, tol):
     m.close()
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 5e-6), ("bf16", 2e-2)])
 def test_unet_tiny2_encoder_attention(td, orc, golden, dtype, tol):
     g = golden("unet")
     cfg = orc["unet"].tiny_config(64, 2, attn_resolutions=[128])
@@ -152,7 +154,7 @@ def base_models(td, orc):
     return {d: td.EDMUnet2D(**cfg, dtype=d).load_state_dict(sd) for d in ("fp32", "bf16")}
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 5e-6), ("bf16", 2e-2)])
 def test_unet_base_forward(td, orc, golden, base_models, dtype, tol):
     g = golden("unet")
     x = torch.from_numpy(orc["rng"].standard_normal(7, (1, 5, 64, 64))).cuda()
@@ -172,7 +174,7 @@ def _sample(td, m, H, W, steps, tile, seed, **kw):
                                     histogram_raw=torch.zeros(1, 5), steps=steps, tile_size=tile, noise_seed=seed, **kw)
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("bf16", 2e-2)])
 def test_tiled_sampler_tiny(td, orc, golden, dtype, tol):
     g = golden("sampling")
     cfg = orc["unet"].tiny_config(64, 1)
@@ -187,7 +189,7 @@ def test_tiled_sampler_tiny(td, orc, golden, dtype, tol):
     m.close()
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("bf16", 2e-2)])
 def test_consistency_sampler_tiny(td, orc, golden, dtype, tol):
     from oracle import tiling
     g = golden("sampling")
@@ -200,7 +202,7 @@ def test_consistency_sampler_tiny(td, orc, golden, dtype, tol):
     m.close()
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("bf16", 2e-2)])
 def test_base_tile_20_steps(td, golden, base_models, dtype, tol):
     """BASELINE config 2 (single 64x64 latent tile, 20 EDM steps) vs the reference's own output."""
     g = golden("sampling")
@@ -229,3 +231,36 @@ def test_blend_properties(td, orc):
             for j in ws:
                 wref[i:i + size, j:j + size] += ww
         assert torch.equal(canvas[5].cpu(), wref)
+
+
+def test_engine_side_fold_mode(td, orc, golden):
+    """fold="engine" (fp64 normalisation inside the engine) differs from the reference only by the rounding of torch's fp32
+    vector_norm over multi-million-element weights (coherent ~3e-6 per large conv): stays within 1e-4 of the reference."""
+    g = golden("unet")
+    cfg = orc["unet"].tiny_config(64, 1)
+    m = td.EDMUnet2D(**cfg, dtype="fp32")
+    m.load_state_dict(orc["unet"].synth_state_dict(cfg, seed=77), fold="engine")
+    x = torch.from_numpy(orc["rng"].standard_normal(7, (2, 5, 16, 16))).cuda()
+    y = m(x, torch.tensor([1.2, 0.3]), [torch.from_numpy(orc["rng"].standard_normal(8, (2, 58))).cuda()])
+    assert rel_rms(y.cpu().numpy(), g["tiny_out"]) < 1e-4
+    m.close()
+
+
+def test_per_layer_activations_tiny(td, orc, golden):
+    """every block output of the tiny model vs the reference's forward hooks (fp32 mode, 5e-6 each)."""
+    g = golden("unet")
+    cfg = orc["unet"].tiny_config(64, 1)
+    m = _model(td, orc, cfg, 77, "fp32")
+    x = torch.from_numpy(orc["rng"].standard_normal(7, (2, 5, 16, 16))).cuda()
+    m(x, torch.tensor([1.2, 0.3]), [torch.from_numpy(orc["rng"].standard_normal(8, (2, 58))).cuda()])
+    emb = m.read_activation(2, 16, 16, "@emb").reshape(2, -1)
+    assert rel_rms(emb.numpy(), g["tiny_emb"]) < 5e-6
+    plan = orc["unet"].build_plan(cfg)
+    n = 0
+    for b in plan["enc"] + plan["dec"]:
+        lab = b["name"] if b["kind"] == "conv" else b["name"] + (".attn_proj" if b["attn"] else ".conv_res1")
+        a = m.read_activation(2, 16, 16, lab)
+        assert rel_rms(a.numpy(), g["tiny_tap:" + b["name"]]) < 5e-6, b["name"]
+        n += 1
+    assert n == 21
+    m.close()
