@@ -63,6 +63,9 @@ int td_engine_set_option(td_engine* e, const char* key, int64_t value);
  * conv_igemm launch (and every other U-Net kernel); this reads/reset the accumulated kernel time and launch counts. */
 int td_engine_profile_read(td_engine* e, double* conv_ms, int64_t* conv_launches, double* other_ms, int64_t* other_launches, int reset);
 
+/* per-op breakdown of the same counters as text lines "label<TAB>ms<TAB>launches" (call before a resetting read) */
+int td_engine_profile_dump(td_engine* e, char* buf, int64_t capacity);
+
 /* ---- model ------------------------------------------------------------------------------------------------
  * Replaces EDMUnet2D(...) + load_state_dict (edm_unet.py:17-143; diffusers layout, SURVEY.md §8b face 3).
  * Weights are the reference's RAW fp32 parameters by state-dict name; the engine folds the magnitude-preserving

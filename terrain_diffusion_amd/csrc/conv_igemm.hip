@@ -15,11 +15,33 @@
 //   * bf16: v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  fp32: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
 #include "td_device.h"
 
+// ablation hooks for tools/conv_bench.hip (-DTD_ABLATE_x); no-ops in the product build
+#ifdef TD_ABLATE_BLOAD
+#define TD_ABL_BLOAD(X)
+#else
+#define TD_ABL_BLOAD(X) X
+#endif
+#ifdef TD_ABLATE_BARRIER
+#define TD_ABL_BARRIER(X)
+#else
+#define TD_ABL_BARRIER(X) X
+#endif
+#ifdef TD_ABLATE_BSTORE
+#define TD_ABL_BSTORE(X)
+#else
+#define TD_ABL_BSTORE(X) X
+#endif
+
+// LDS rows are 128 bytes = eight 16-byte slots; slot index is XOR-ed with TD_SWZ(row) (row = patch pixel or cout-in-tile).
+// ((row >> 1) & 7) is conflict-free for both the 16-row (16x16 MFMA) and the 32-row (32x32 MFMA) ds_read_b128 fragment reads.
+#define TD_SWZ(r) (((r) >> 1) & 7)
+
 namespace td {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native 16-byte register piece (HIP's u32x4 struct defeats SROA -> scratch)
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -34,18 +56,18 @@ template <> struct Elem<__bf16> {
 };
 
 // mp_silu(s*x) on one 16-byte piece
-template <typename T> __device__ __forceinline__ uint4 xform_piece(uint4 v, float s);
-template <> __device__ __forceinline__ uint4 xform_piece<float>(uint4 v, float s) {
+template <typename T> __device__ __forceinline__ u32x4 xform_piece(u32x4 v, float s);
+template <> __device__ __forceinline__ u32x4 xform_piece<float>(u32x4 v, float s) {
     f32x4 f = __builtin_bit_cast(f32x4, v);
 #pragma unroll
     for (int i = 0; i < 4; ++i) f[i] = Elem<float>::silu(f[i] * s);
-    return __builtin_bit_cast(uint4, f);
+    return __builtin_bit_cast(u32x4, f);
 }
-template <> __device__ __forceinline__ uint4 xform_piece<__bf16>(uint4 v, float s) {
+template <> __device__ __forceinline__ u32x4 xform_piece<__bf16>(u32x4 v, float s) {
     bf16x8 h = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
     for (int i = 0; i < 8; ++i) h[i] = (__bf16)Elem<__bf16>::silu((float)h[i] * s);
-    return __builtin_bit_cast(uint4, h);
+    return __builtin_bit_cast(u32x4, h);
 }
 
 __device__ __forceinline__ int src_pixel(int n, int y, int x, int Hs, int Ws, int resample) {
@@ -65,20 +87,18 @@ template <> __device__ __forceinline__ f32x4 load4<__bf16>(const void* base, siz
 }
 
 // Shared epilogue: transform 4 consecutive couts of one output pixel, store, return sum of squares of what was stored.
+// `aux` = the 4 modulation values c[n][co..] (EPI_EMB_SILU) or the 4 residual values (EPI_RESIDUAL with p.res), fetched by the caller.
 template <typename T>
-__device__ __forceinline__ float epilogue4(const ConvParams& p, int n, int y, int x, int co, f32x4 v, float rn) {
+__device__ __forceinline__ float epilogue4(const ConvParams& p, int n, int y, int x, int co, f32x4 v, float rn, f32x4 aux) {
     const int pix = (n * p.H + y) * p.W + x;
     if (p.epi == EPI_EMB_SILU) {
-        f32x4 c = *(const f32x4*)(p.cvec + (size_t)n * p.cvec_stride + co);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = Elem<T>::silu(v[k] * c[k]);
+        for (int k = 0; k < 4; ++k) v[k] = Elem<T>::silu(v[k] * aux[k]);
     } else if (p.epi == EPI_RESIDUAL) {
         if (p.res) {
-            int sp = src_pixel(n, y, x, p.res_Hs, p.res_Ws, p.res_resample);
-            f32x4 r = load4<T>(p.res, (size_t)sp * p.res_cstride + co);
-            float s = p.res_scale * rn;
+            const float s = p.res_scale * rn;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] += s * r[k];
+            for (int k = 0; k < 4; ++k) v[k] += s * aux[k];
         }
         if (p.clip > 0.f) {
 #pragma unroll
@@ -111,7 +131,58 @@ __device__ __forceinline__ float pixel_rn(const float* sumsq, int nparts, size_t
     return 1.f / (1e-4f + sqrtf(s * inv_c));  // mp_layers.py:9-12 with dim=1: x / (eps + ||x||_c / sqrt(C))
 }
 
-template <typename T, int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N>
+// One K-step (one tap of one 128-byte channel chunk) of MFMAs: weights from sb, activations from the patch sa shifted by doff.
+template <typename T, int MT, int NTL>
+__device__ __forceinline__ void mfma_tap(const unsigned char* __restrict__ sa, const unsigned char* __restrict__ sb, const int (&base_pp)[MT],
+                                         const int (&nloc)[NTL], int doff, int lg, f32x4 (&acc)[MT][NTL]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int kg = ks * 4 + lg;
+        u32x4 wf[NTL], xf[MT];
+#ifdef TD_ABLATE_DSREAD
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) { wf[j] = u32x4{(unsigned)kg, 1u, 2u, 3u}; asm volatile("" : "+v"(wf[j])); }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) { xf[i] = u32x4{(unsigned)doff, 1u, 2u, 3u}; asm volatile("" : "+v"(xf[i])); }
+#else
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) wf[j] = *(const u32x4*)(sb + nloc[j] * 128 + ((kg ^ TD_SWZ(nloc[j])) << 4));
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int pp = base_pp[i] + doff;
+            xf[i] = *(const u32x4*)(sa + pp * 128 + ((kg ^ TD_SWZ(pp)) << 4));
+        }
+#endif
+#ifdef TD_ABLATE_MFMA
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) asm volatile("" :: "v"(wf[j]));
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("" :: "v"(xf[i]));
+#else
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, xf[i]), acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, wf[j])[e], __builtin_bit_cast(f32x4, xf[i])[e], acc[i][j], 0, 0, 0);
+        }
+#endif
+    }
+}
+
+// FLAVOR 0 ("tap"): one weight tile per K-step, double-buffered, one barrier per tap — for large pixel counts.
+// FLAVOR 1 ("stream"): all 9 tap tiles of a K-group staged at once (next group's 9 tiles + patch prefetched into registers while
+//   the current group multiplies), two barriers per group — for small pixel counts (batch 1), where each workgroup is bound by
+//   the latency of streaming its own slice of the weights from HBM.
+template <typename T, int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N, int FLAVOR>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(const ConvParams p) {
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
     constexpr int TPIX = TH * TW;
@@ -121,12 +192,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     constexpr int CHUNK = Elem<T>::CHUNK, PER16 = Elem<T>::PER16;
     constexpr int A_ITERS = (NPATCH * 8 + NTHR - 1) / NTHR;
     constexpr int B_ITERS = (BN * 8) / NTHR;
+    constexpr int A_BYTES = NPATCH * 128, B_BYTES = BN * 128;
     static_assert(BM % (16 * WAVES_M) == 0 && BN % (16 * WAVES_N) == 0 && (BN * 8) % NTHR == 0, "tile shape");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* s_a = smem;
-    unsigned char* s_b = smem + NPATCH * 128;
-    float* s_rn = (float*)(s_b + 2 * BN * 128);
+    constexpr int NA = FLAVOR == 0 ? 2 : 1, NB = FLAVOR == 0 ? 2 : 9, BR = FLAVOR == 0 ? 1 : 9;
+    unsigned char* s_a = smem;                        // activation-patch buffer(s)
+    unsigned char* s_b = smem + NA * A_BYTES;         // weight-tile buffers
+    float* s_rn = (float*)(s_b + NB * B_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -141,17 +214,87 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     const int n0 = ig * NIMG, y0 = tyi * TH, x0 = txi * TW, co0 = ntile * BN;
     const int g0 = (int)((long)ksp * p.kgroups / p.ksplit), g1 = (int)((long)(ksp + 1) * p.kgroups / p.ksplit);
 
-    // ---- per-thread staging coordinates (constant over the K loop): packed (n, y+1, x+1, interior) or -1
+    // ---- locate the first K group: (segment, chunk) and its first kstep
+    int seg = 0, chunk = 0, kstep = 0;
+    {
+        int g = 0;
+        while (seg < p.nseg) {
+            const int nch = p.seg[seg].C / CHUNK;
+            if (g0 < g + nch) { chunk = g0 - g; kstep += chunk * p.seg[seg].taps; break; }
+            g += nch; kstep += nch * p.seg[seg].taps; ++seg;
+        }
+    }
+
+    // ---- weights of the first kstep are independent of everything else: get them in flight first
+    u32x4 breg[BR * B_ITERS];
+    const int kstep_last = p.kgroups == 0 ? 0 : [&] { int t_ = 0; for (int s_ = 0; s_ < p.nseg; ++s_) t_ += (p.seg[s_].C / CHUNK) * p.seg[s_].taps; return t_ - 1; }();
+#define TD_LOAD_B(DST, KS)                                                                             \
+    {                                                                                                  \
+        const int ks_ = (KS) < kstep_last ? (KS) : kstep_last;                                         \
+        const u32x4* wsrc_ = (const u32x4*)p.wpack + ((size_t)ks_ * p.CoutPad + co0) * 8 + tid;        \
+        _Pragma("unroll") for (int i_ = 0; i_ < B_ITERS; ++i_) DST[i_] = wsrc_[i_ * NTHR];             \
+    }
+#define TD_LOAD_B_GROUP(KS, TAPS)                                                                      \
+    {                                                                                                  \
+        _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_)                                               \
+            if (t_ < (TAPS)) {                                                                         \
+                const u32x4* wsrc_ = (const u32x4*)p.wpack + ((size_t)((KS) + t_) * p.CoutPad + co0) * 8 + tid; \
+                _Pragma("unroll") for (int i_ = 0; i_ < B_ITERS; ++i_) breg[t_ * B_ITERS + i_] = wsrc_[i_ * NTHR]; \
+            }                                                                                          \
+    }
+#define TD_STORE_B_GROUP(TAPS)                                                                         \
+    {                                                                                                  \
+        _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_)                                               \
+            if (t_ < (TAPS)) {                                                                         \
+                _Pragma("unroll") for (int i_ = 0; i_ < B_ITERS; ++i_)                                 \
+                    *(u32x4*)(s_b + t_ * B_BYTES + (tid + i_ * NTHR) * 16) = breg[t_ * B_ITERS + i_];  \
+            }                                                                                          \
+    }
+    if constexpr (FLAVOR == 0) { TD_LOAD_B(breg, kstep); } else { TD_LOAD_B_GROUP(kstep, p.seg[seg].taps); }
+
+    // ---- per-thread staging coordinates (constant over the K loop): packed (n, y, x, interior) or -1
     int a_coord[A_ITERS];
 #pragma unroll
     for (int it = 0; it < A_ITERS; ++it) {
-        int e = tid + it * NTHR, pp = e >> 3;
-        int img = pp / PPI, r = pp % PPI, py = r / PW, px = r % PW;
-        int n = n0 + img, y = y0 + py - 1, x = x0 + px - 1;
-        bool ok = (pp < NPATCH) && n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W;
-        bool interior = py >= 1 && py <= TH && px >= 1 && px <= TW;
+        const int e = tid + it * NTHR, pp = e >> 3;
+        const int img = pp / PPI, r = pp % PPI, py = r / PW, px = r % PW;
+        const int n = n0 + img, y = y0 + py - 1, x = x0 + px - 1;
+        const bool ok = (pp < NPATCH) && n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        const bool interior = py >= 1 && py <= TH && px >= 1 && px <= TW;
         a_coord[it] = ok ? ((n << 21) | (y << 11) | (x << 1) | (interior ? 1 : 0)) : -1;
     }
+    u32x4 av[A_ITERS];
+#define TD_LOAD_A(SEG, CH)                                                                                            \
+    {                                                                                                                 \
+        const ConvSeg& sg_ = p.seg[SEG];                                                                              \
+        const T* src_ = (const T*)sg_.src + (CH) * CHUNK + (tid & 7) * PER16;                                         \
+        _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) {                                                   \
+            const int c_ = a_coord[it_];                                                                              \
+            av[it_] = u32x4{0u, 0u, 0u, 0u};                                                                          \
+            if (c_ >= 0 && (sg_.taps == 9 || (c_ & 1))) {                                                             \
+                const int sp_ = src_pixel(c_ >> 21, (c_ >> 11) & 1023, (c_ >> 1) & 1023, sg_.Hs, sg_.Ws, sg_.resample); \
+                av[it_] = *(const u32x4*)(src_ + (size_t)sp_ * sg_.cstride);                                          \
+            }                                                                                                         \
+        }                                                                                                             \
+    }
+#define TD_STORE_A(SEG, BUF)                                                                           \
+    {                                                                                                  \
+        const ConvSeg& sg_ = p.seg[SEG];                                                               \
+        unsigned char* dst_ = s_a + (BUF) * A_BYTES;                                                   \
+        _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) {                                    \
+            const int e_ = tid + it_ * NTHR, pp_ = e_ >> 3, slot_ = e_ & 7;                            \
+            if (pp_ < NPATCH) {                                                                        \
+                u32x4 v_ = av[it_];                                                                    \
+                if (sg_.xform != 0 && a_coord[it_] >= 0) {                                             \
+                    float s_ = sg_.scale;                                                              \
+                    if (sg_.xform == 2) s_ *= s_rn[pp_];                                               \
+                    v_ = xform_piece<T>(v_, s_);                                                       \
+                }                                                                                      \
+                *(u32x4*)(dst_ + pp_ * 128 + ((slot_ ^ TD_SWZ(pp_)) << 4)) = v_;                        \
+            }                                                                                          \
+        }                                                                                              \
+    }
+    if (g0 < g1) TD_LOAD_A(seg, chunk);
 
     // ---- per-pixel 1/(eps + rms) of the pixel-normed source, for the patch pixels
     const float* rn_sumsq = nullptr; int rn_parts = 0, rn_Hs = 0, rn_Ws = 0, rn_res = 0; float rn_invc = 0.f;
@@ -160,8 +303,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     if (rn_sumsq) {
         const size_t npix = (size_t)p.N * rn_Hs * rn_Ws;
         for (int pp = tid; pp < NPATCH; pp += NTHR) {
-            int img = pp / PPI, r = pp % PPI, py = r / PW, px = r % PW;
-            int n = n0 + img, y = y0 + py - 1, x = x0 + px - 1;
+            const int img = pp / PPI, r = pp % PPI, py = r / PW, px = r % PW;
+            const int n = n0 + img, y = y0 + py - 1, x = x0 + px - 1;
             float rn = 0.f;
             if (n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W)
                 rn = pixel_rn(rn_sumsq, rn_parts, npix, src_pixel(n, y, x, rn_Hs, rn_Ws, rn_res), rn_invc);
@@ -173,8 +316,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     int base_pp[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        int q = wm * WM + i * 16 + lr;
-        int img = q / TPIX, r = q % TPIX, ty = r / TW, tx = r % TW;
+        const int q = wm * WM + i * 16 + lr;
+        const int img = q / TPIX, r = q % TPIX, ty = r / TW, tx = r % TW;
         base_pp[i] = img * PPI + (ty + 1) * PW + (tx + 1);
     }
     int nloc[NTL];
@@ -182,7 +325,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     for (int j = 0; j < NTL; ++j) nloc[j] = wn * WN + j * 16 + lr;
 
     // fp32 mode accumulates each K-group (one chunk x taps, <= 288 products) in a fresh accumulator and adds it to the running
-    // total afterwards: a single k-ordered fp32 chain over K ~ 14k costs ~3e-6 rel. error per conv (measured 2.9e-5 per forward).
+    // total afterwards, which keeps the fp32 summation error at the level of a blocked CPU conv.
     constexpr bool TWO_LEVEL = sizeof(T) == 4;
     f32x4 acc[MT][NTL];
     f32x4 tot[TWO_LEVEL ? MT : 1][TWO_LEVEL ? NTL : 1];
@@ -194,108 +337,84 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
             if constexpr (TWO_LEVEL) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
-    // ---- locate first group: (segment, chunk) and its first kstep
-    int seg = 0, chunk = 0, kstep = 0;
-    {
-        int g = 0;
-        while (seg < p.nseg) {
-            int nch = p.seg[seg].C / CHUNK;
-            if (g0 < g + nch) { chunk = g0 - g; kstep += chunk * p.seg[seg].taps; break; }
-            g += nch; kstep += nch * p.seg[seg].taps; ++seg;
-        }
-    }
-
-    uint4 breg[B_ITERS];
-    auto load_b = [&](int ks_) {
-        const uint4* wsrc = (const uint4*)p.wpack + ((size_t)ks_ * p.CoutPad + co0) * 8;
+    __syncthreads();  // s_rn visible
+    if (g0 < g1) TD_STORE_A(seg, 0);
+    if constexpr (FLAVOR == 1) {
+        if (g0 < g1) TD_STORE_B_GROUP(p.seg[seg].taps);
+        for (int g = g0; g < g1; ++g) {
+            const int taps = p.seg[seg].taps;
+            int nseg_ = seg, nchunk_ = chunk + 1;
+            if (nchunk_ == p.seg[seg].C / CHUNK) { nchunk_ = 0; ++nseg_; }
+            const bool has_next = g + 1 < g1;
+            kstep += taps;
+            if (has_next) {  // next group's 9 weight tiles and patch fly while this group multiplies
+                TD_LOAD_B_GROUP(kstep, p.seg[nseg_].taps);
+                TD_LOAD_A(nseg_, nchunk_);
+            }
+            __syncthreads();
+            if (taps == 9) {
 #pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) breg[i] = wsrc[tid + i * NTHR];
-    };
-    if (g0 < g1) load_b(kstep);
-    int buf = 0;
+                for (int tap = 0; tap < 9; ++tap) mfma_tap<T, MT, NTL>(s_a, s_b + tap * B_BYTES, base_pp, nloc, (tap / 3 - 1) * PW + (tap % 3 - 1), lg, acc);
+            } else {
+                mfma_tap<T, MT, NTL>(s_a, s_b, base_pp, nloc, 0, lg, acc);
+            }
+            if (has_next) {
+                __syncthreads();
+                TD_STORE_A(nseg_, 0);
+                TD_STORE_B_GROUP(p.seg[nseg_].taps);
+            }
+            if constexpr (TWO_LEVEL) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) { tot[i][j] += acc[i][j]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            }
+            seg = nseg_; chunk = nchunk_;
+        }
+    } else {
+    int abuf = 0, bbuf = 0;
 
     for (int g = g0; g < g1; ++g) {
-        const ConvSeg& sg = p.seg[seg];
-        const int taps = sg.taps;
-        // ---------------- stage the activation patch of (seg, chunk)
-        {
-            uint4 av[A_ITERS];
-            const T* src = (const T*)sg.src;
+        const int taps = p.seg[seg].taps;
+        // next group's (segment, chunk); its activation patch is fetched now and lands in the other buffer after this group's taps
+        int nseg_ = seg, nchunk_ = chunk + 1;
+        if (nchunk_ == p.seg[seg].C / CHUNK) { nchunk_ = 0; ++nseg_; }
+        const bool has_next = g + 1 < g1;
+        if (has_next) TD_LOAD_A(nseg_, nchunk_);
+        const unsigned char* sa = s_a + abuf * A_BYTES;
+#define TD_TAP(DOFF, MORE)                                                                              \
+    {                                                                                                   \
+        unsigned char* sb_ = s_b + bbuf * B_BYTES;                                                      \
+        TD_ABL_BSTORE(_Pragma("unroll") for (int i_ = 0; i_ < B_ITERS; ++i_) *(u32x4*)(sb_ + (tid + i_ * NTHR) * 16) = breg[i_]); \
+        ++kstep;                                                                                        \
+        TD_ABL_BLOAD(TD_LOAD_B(breg, kstep));                                                           \
+        TD_ABL_BARRIER(__syncthreads());                                                                                \
+        mfma_tap<T, MT, NTL>(sa, sb_, base_pp, nloc, (DOFF), lg, acc);                                  \
+        bbuf ^= 1;                                                                                      \
+    }
+        if (taps == 9) {
 #pragma unroll
-            for (int it = 0; it < A_ITERS; ++it) {
-                int c = a_coord[it];
-                av[it] = uint4{0u, 0u, 0u, 0u};
-                if (c >= 0 && (taps == 9 || (c & 1))) {
-                    int n = c >> 21, y = (c >> 11) & 1023, x = (c >> 1) & 1023;
-                    int sp = src_pixel(n, y, x, sg.Hs, sg.Ws, sg.resample);
-                    int slot = (tid + it * NTHR) & 7;
-                    av[it] = *(const uint4*)(src + (size_t)sp * sg.cstride + chunk * CHUNK + slot * PER16);
-                }
-            }
-            __syncthreads();  // everyone is done reading s_a (previous group's last tap) and s_rn is written
-#pragma unroll
-            for (int it = 0; it < A_ITERS; ++it) {
-                int e = tid + it * NTHR, pp = e >> 3, slot = e & 7;
-                if (pp < NPATCH) {
-                    uint4 v = av[it];
-                    if (sg.xform != 0 && a_coord[it] >= 0) {
-                        float s = sg.scale;
-                        if (sg.xform == 2) s *= s_rn[pp];
-                        v = xform_piece<T>(v, s);
-                    }
-                    *(uint4*)(s_a + pp * 128 + ((slot ^ (pp & 7)) << 4)) = v;
-                }
-            }
+            for (int tap = 0; tap < 9; ++tap) TD_TAP((tap / 3 - 1) * PW + (tap % 3 - 1), (tap < 8) || has_next);
+        } else {
+            TD_TAP(0, has_next);
         }
-        // ---------------- taps
-        for (int tap = 0; tap < taps; ++tap) {
-            unsigned char* sb = s_b + buf * (BN * 128);
-#pragma unroll
-            for (int i = 0; i < B_ITERS; ++i) *(uint4*)(sb + (tid + i * NTHR) * 16) = breg[i];
-            ++kstep;
-            const bool more = (tap + 1 < taps) || (g + 1 < g1);
-            if (more) load_b(kstep);  // next kstep's weights fly during this tap's MFMAs
-            __syncthreads();
-            const int dy = (taps == 9) ? (tap / 3 - 1) : 0, dx = (taps == 9) ? (tap % 3 - 1) : 0;
-            const int doff = dy * PW + dx;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int kg = ks * 4 + lg;
-                uint4 wf[NTL], xf[MT];
-#pragma unroll
-                for (int j = 0; j < NTL; ++j) wf[j] = *(const uint4*)(sb + nloc[j] * 128 + ((kg ^ (nloc[j] & 7)) << 4));
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    int pp = base_pp[i] + doff;
-                    xf[i] = *(const uint4*)(s_a + pp * 128 + ((kg ^ (pp & 7)) << 4));
-                }
-                if constexpr (sizeof(T) == 2) {
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int j = 0; j < NTL; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, xf[i]), acc[i][j], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int i = 0; i < MT; ++i)
-#pragma unroll
-                            for (int j = 0; j < NTL; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, wf[j])[e], __builtin_bit_cast(f32x4, xf[i])[e], acc[i][j], 0, 0, 0);
-                }
-            }
-            buf ^= 1;
-        }
+        if (has_next) TD_STORE_A(nseg_, abuf ^ 1);
+        abuf ^= 1;
         if constexpr (TWO_LEVEL) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NTL; ++j) { tot[i][j] += acc[i][j]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         }
-        // next group
-        if (++chunk == sg.C / CHUNK) { chunk = 0; ++seg; }
+        seg = nseg_; chunk = nchunk_;
     }
+    }
+#undef TD_TAP
+#undef TD_LOAD_A
+#undef TD_STORE_A
+#undef TD_LOAD_B
+#undef TD_LOAD_B_GROUP
+#undef TD_STORE_B_GROUP
     if constexpr (TWO_LEVEL) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -307,33 +426,40 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     const size_t M = (size_t)p.N * p.H * p.W;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        int q = wm * WM + i * 16 + lr;
-        int img = q / TPIX, r = q % TPIX, ty = r / TW, tx = r % TW;
-        int n = n0 + img, y = y0 + ty, x = x0 + tx;
-        bool ok = n < p.N && y < p.H && x < p.W;
+        const int q = wm * WM + i * 16 + lr;
+        const int img = q / TPIX, r = q % TPIX, ty = r / TW, tx = r % TW;
+        const int n = n0 + img, y = y0 + ty, x = x0 + tx;
+        const bool ok = n < p.N && y < p.H && x < p.W;
         float ss = 0.f;
         if (ok) {
             if (p.ksplit > 1) {
-                size_t pix = ((size_t)n * p.H + y) * p.W + x;
+                const size_t pix = ((size_t)n * p.H + y) * p.W + x;
 #pragma unroll
                 for (int j = 0; j < NTL; ++j) {
-                    int co = co0 + wn * WN + j * 16 + lg * 4;
+                    const int co = co0 + wn * WN + j * 16 + lg * 4;
                     *(f32x4*)(p.partial + ((size_t)ksp * M + pix) * p.CoutPad + co) = acc[i][j];
                 }
             } else {
-                float rn = (p.res_sumsq != nullptr) ? s_rn[base_pp[i]] : 1.f;
+                const float rn = (p.res_sumsq != nullptr) ? s_rn[base_pp[i]] : 1.f;
+                const int cobase = co0 + wn * WN + lg * 4;
+                f32x4 aux[NTL];  // residual / modulation operands fetched together, then consumed
+                if (p.epi == EPI_EMB_SILU) {
 #pragma unroll
-                for (int j = 0; j < NTL; ++j) {
-                    int co = co0 + wn * WN + j * 16 + lg * 4;
-                    ss += epilogue4<T>(p, n, y, x, co, acc[i][j], rn);
+                    for (int j = 0; j < NTL; ++j) aux[j] = *(const f32x4*)(p.cvec + (size_t)n * p.cvec_stride + cobase + j * 16);
+                } else if (p.epi == EPI_RESIDUAL && p.res) {
+                    const int sp = src_pixel(n, y, x, p.res_Hs, p.res_Ws, p.res_resample);
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) aux[j] = load4<T>(p.res, (size_t)sp * p.res_cstride + cobase + j * 16);
                 }
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) ss += epilogue4<T>(p, n, y, x, cobase + j * 16, acc[i][j], rn, aux[j]);
             }
         }
         if (p.out_sumsq && p.ksplit == 1) {
             ss += __shfl_xor(ss, 16);
             ss += __shfl_xor(ss, 32);
             if (ok && lg == 0) {
-                size_t pix = ((size_t)n * p.H + y) * p.W + x;
+                const size_t pix = ((size_t)n * p.H + y) * p.W + x;
                 p.out_sumsq[(size_t)(ntile * WAVES_N + wn) * M + pix] = ss;
             }
         }
@@ -358,7 +484,10 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
             f32x4 t = *(const f32x4*)(p.partial + ((size_t)k * M + pix) * p.CoutPad + co);
             v += t;
         }
-        ss += epilogue4<T>(p, n, y, x, co, v, rn);
+        f32x4 aux = {0.f, 0.f, 0.f, 0.f};
+        if (p.epi == EPI_EMB_SILU) aux = *(const f32x4*)(p.cvec + (size_t)n * p.cvec_stride + co);
+        else if (p.epi == EPI_RESIDUAL && p.res) aux = load4<T>(p.res, (size_t)src_pixel(n, y, x, p.res_Hs, p.res_Ws, p.res_resample) * p.res_cstride + co);
+        ss += epilogue4<T>(p, n, y, x, co, v, rn, aux);
     }
     if (p.out_sumsq) {
 #pragma unroll
@@ -368,13 +497,17 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
 }
 
 // ------------------------------------------------------------------------------------------ host launcher
-template <typename T, int TH, int TW, int NIMG, int BN>
+template <typename T, int TH, int TW, int NIMG, int BN, int FLAVOR>
 static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
     constexpr int WAVES_M = 2, WAVES_N = 2;
     constexpr int NPATCH = NIMG * (TH + 2) * (TW + 2);
-    size_t lds = (size_t)NPATCH * 128 + 2 * BN * 128 + NPATCH * 4;
+    size_t lds = (size_t)(FLAVOR == 0 ? 2 : 1) * NPATCH * 128 + (FLAVOR == 0 ? 2 : 9) * BN * 128 + NPATCH * 4;
     int grid = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * p.ksplit;
-    auto kern = conv_igemm_kernel<T, TH, TW, NIMG, BN, WAVES_M, WAVES_N>;
+    auto kern = conv_igemm_kernel<T, TH, TW, NIMG, BN, WAVES_M, WAVES_N, FLAVOR>;
+    if (lds > 65536) {
+        static bool attr_set = false;  // per instantiation
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES_M * WAVES_N), lds, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -387,14 +520,25 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
 }
 
 // Tile geometry is chosen by the plan builder and recorded in the params (tiles_x/tiles_y/img_groups/n_ntiles);
-// `narrow` selects the 8x8x2 tile for feature maps narrower than 16, `bn` the cout tile.
-hipError_t launch_conv(const ConvParams& p, bool is_bf16, bool narrow, int bn, hipStream_t st) {
-    if (is_bf16) {
-        if (!narrow) return bn == 128 ? launch_cfg<__bf16, 8, 16, 1, 128>(p, st) : launch_cfg<__bf16, 8, 16, 1, 64>(p, st);
-        return bn == 128 ? launch_cfg<__bf16, 8, 8, 2, 128>(p, st) : launch_cfg<__bf16, 8, 8, 2, 64>(p, st);
+// `narrow` selects the 8x8x2 tile for feature maps narrower than 16, `bn` the cout tile (64, 96 or 128; 192 spills registers).
+template <typename T>
+static hipError_t launch_t(const ConvParams& p, bool narrow, int bn, int flavor, hipStream_t st) {
+    (void)flavor;
+    if (!narrow) {
+        switch (bn) {
+            case 128: return launch_cfg<T, 8, 16, 1, 128, 0>(p, st);
+            case 96: return launch_cfg<T, 8, 16, 1, 96, 0>(p, st);
+            default: return launch_cfg<T, 8, 16, 1, 64, 0>(p, st);
+        }
     }
-    if (!narrow) return bn == 128 ? launch_cfg<float, 8, 16, 1, 128>(p, st) : launch_cfg<float, 8, 16, 1, 64>(p, st);
-    return bn == 128 ? launch_cfg<float, 8, 8, 2, 128>(p, st) : launch_cfg<float, 8, 8, 2, 64>(p, st);
+    switch (bn) {
+        case 128: return launch_cfg<T, 8, 8, 2, 128, 0>(p, st);
+        case 96: return launch_cfg<T, 8, 8, 2, 96, 0>(p, st);
+        default: return launch_cfg<T, 8, 8, 2, 64, 0>(p, st);
+    }
+}
+hipError_t launch_conv(const ConvParams& p, bool is_bf16, bool narrow, int bn, int flavor, hipStream_t st) {
+    return is_bf16 ? launch_t<__bf16>(p, narrow, bn, flavor, st) : launch_t<float>(p, narrow, bn, flavor, st);
 }
 
 }  // namespace td

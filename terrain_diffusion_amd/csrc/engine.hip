@@ -15,6 +15,7 @@
 
 // single translation unit: kernels are compiled together with the host runtime
 #include "conv_igemm.hip"
+#include "conv_glds.hip"
 #include "small_kernels.hip"
 
 using namespace td;
@@ -68,6 +69,7 @@ struct td_engine {
     // "profile" option: HIP events around every conv launch (eager mode), accumulated here
     double prof_conv_ms = 0.0, prof_other_ms = 0.0;
     int64_t prof_conv_launches = 0, prof_other_launches = 0;
+    std::map<std::string, std::pair<double, int64_t>> prof_ops;  // label -> (ms, launches)
     int64_t option(const char* k, int64_t dflt) const { auto it = opt.find(k); return it == opt.end() ? dflt : it->second; }
 };
 
@@ -147,6 +149,7 @@ struct Op {
     ConvParams p;
     bool narrow = false;
     int bn = 64;
+    int flavor = 0;            // 0: per-tap register-staged kernel (conv_igemm.hip); 2: LDS-DMA throughput kernel (conv_glds.hip)
     int cvec_off = -1;         // EPI_EMB_SILU: offset of this block's c vector
     int out_C = 0, out_H = 0, out_W = 0;  // output tensor geometry (debug read-back)
     // ATTN
@@ -308,7 +311,7 @@ static int pack_conv(td_unet* u, ConvWeights& cw) {
             for (int tap = 0; tap < s.taps; ++tap, ++kstep)
                 for (int co = 0; co < cw.cout; ++co)
                     for (int q = 0; q < 8; ++q) {
-                        const size_t dst = ((size_t)kstep * cw.cout_pad + co) * row_elems + (size_t)((q ^ (co & 7)) * per16);
+                        const size_t dst = ((size_t)kstep * cw.cout_pad + co) * row_elems + (size_t)((q ^ TD_SWZ(co)) * per16);
                         for (int e = 0; e < per16; ++e) {
                             int ci = ch * chunk + q * per16 + e;
                             float v = 0.f;
@@ -318,7 +321,7 @@ static int pack_conv(td_unet* u, ConvWeights& cw) {
                     }
     }
     cw.packed.reset(new DevBuf());
-    HIP_TRY(cw.packed->alloc(total * u->esize(), false));
+    HIP_TRY(cw.packed->alloc(total * u->esize() + 8192, true));  // tail padding: the LDS-DMA kernel may over-read 32 rows
     HIP_TRY(hipMemcpy(cw.packed->p, u->bf16 ? (const void*)stage16.data() : (const void*)stage.data(), total * u->esize(), hipMemcpyHostToDevice));
     return TD_OK;
 }
@@ -490,14 +493,29 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
         p.wpack = cw.packed->p;
         p.N = N; p.H = h; p.W = w; p.Cout = cw.cout; p.CoutPad = cw.cout_pad; p.kgroups = kgroups;
         op.narrow = w < 16;
-        const int TH = 8, TW = op.narrow ? 8 : 16, NIMG = op.narrow ? 2 : 1;
-        p.tiles_x = (w + TW - 1) / TW; p.tiles_y = (h + TH - 1) / TH; p.img_groups = (N + NIMG - 1) / NIMG;
-        const int64_t mt = (int64_t)p.tiles_x * p.tiles_y * p.img_groups;
-        op.bn = (cw.cout_pad % 128 == 0 && mt * (cw.cout_pad / 128) >= bn128_min) ? 128 : 64;
-        p.n_ntiles = cw.cout_pad / op.bn;
-        const int64_t base = mt * p.n_ntiles;
-        p.ksplit = 1;
-        if (use_splitk && base < splitk_target / 2 && kgroups > 1) p.ksplit = (int)std::min<int64_t>(kgroups, (splitk_target + base - 1) / base);
+        // throughput flavour (bf16): 256-pixel tiles x 192/128 couts, needs enough workgroups to fill the 256 CUs
+        {
+            const int TH2 = op.narrow ? 8 : 16, TW2 = op.narrow ? 8 : 16, NIMG2 = op.narrow ? 4 : 1;
+            const int bn2 = cw.cout_pad % 128 == 0 ? 128 : (cw.cout_pad % 96 == 0 ? 96 : 0);
+            const int64_t mt2 = (int64_t)((w + TW2 - 1) / TW2) * ((h + TH2 - 1) / TH2) * ((N + NIMG2 - 1) / NIMG2);
+            if (u->bf16 && bn2 && u->eng->option("glds", 1) && mt2 * (cw.cout_pad / bn2) >= u->eng->option("glds_min_wgs", 192)) {
+                op.flavor = 2; op.bn = bn2;
+                p.tiles_x = (w + TW2 - 1) / TW2; p.tiles_y = (h + TH2 - 1) / TH2; p.img_groups = (N + NIMG2 - 1) / NIMG2;
+                p.n_ntiles = cw.cout_pad / bn2; p.ksplit = 1;
+            }
+        }
+        if (op.flavor == 0) {
+            const int TH = 8, TW = op.narrow ? 8 : 16, NIMG = op.narrow ? 2 : 1;
+            p.tiles_x = (w + TW - 1) / TW; p.tiles_y = (h + TH - 1) / TH; p.img_groups = (N + NIMG - 1) / NIMG;
+            const int64_t mt = (int64_t)p.tiles_x * p.tiles_y * p.img_groups;
+            op.bn = 64;
+            if (cw.cout_pad % 128 == 0 && mt * (cw.cout_pad / 128) >= bn128_min) op.bn = 128;
+            else if (cw.cout_pad % 96 == 0 && mt * (cw.cout_pad / 96) >= bn128_min) op.bn = 96;
+            p.n_ntiles = cw.cout_pad / op.bn;
+            const int64_t base = mt * p.n_ntiles;
+            p.ksplit = 1;
+            if (use_splitk && base < splitk_target / 2 && kgroups > 1) p.ksplit = (int)std::min<int64_t>(kgroups, (splitk_target + base - 1) / base);
+        }
         p.epi = epi; p.out_f32 = out_f32 ? 1 : 0; p.clip = clip;
         const int out_parts = p.ksplit > 1 ? 1 : p.n_ntiles * 2;
         if (out_f32) {
@@ -648,34 +666,36 @@ static int run_unet(td_unet* u, Plan& pl, int step) {
     const bool prof = u->eng->option("profile", 0) != 0;
     std::vector<hipEvent_t> evs;
     std::vector<int> ev_kind;
+    std::vector<std::string> ev_label;
     auto mark = [&]() { if (prof) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); evs.push_back(e); } };
     struct Fin {
-        td_unet* u; std::vector<hipEvent_t>& evs; std::vector<int>& kind; hipStream_t st;
+        td_unet* u; std::vector<hipEvent_t>& evs; std::vector<int>& kind; std::vector<std::string>& labels; hipStream_t st;
         ~Fin() {
             if (evs.empty()) return;
             (void)hipStreamSynchronize(st);
             for (size_t i = 0; i + 1 < evs.size(); i += 2) {
                 float ms = 0.f;
                 (void)hipEventElapsedTime(&ms, evs[i], evs[i + 1]);
+                auto& po = u->eng->prof_ops[labels[i / 2]]; po.first += ms; po.second++;
                 if (kind[i / 2] == 0) { u->eng->prof_conv_ms += ms; u->eng->prof_conv_launches++; } else { u->eng->prof_other_ms += ms; u->eng->prof_other_launches++; }
             }
             for (auto e : evs) (void)hipEventDestroy(e);
         }
-    } fin{u, evs, ev_kind, st};
+    } fin{u, evs, ev_kind, ev_label, st};
     for (auto& op : pl.ops) {
         if (op.kind == Op::ATTN) {
             mark();
             if (u->bf16) hipLaunchKernelGGL(attn_kernel<__bf16>, dim3(pl.N, op.C / 64), dim3(256), 0, st, (const __bf16*)op.qkv, (__bf16*)op.att, op.tokens, op.C);
             else hipLaunchKernelGGL(attn_kernel<float>, dim3(pl.N, op.C / 64), dim3(256), 0, st, (const float*)op.qkv, (float*)op.att, op.tokens, op.C);
-            mark(); if (prof) ev_kind.push_back(1);
+            mark(); if (prof) { ev_kind.push_back(1); ev_label.push_back(op.label); }
             HIP_TRY(hipGetLastError());
             continue;
         }
         ConvParams p = op.p;
         if (op.cvec_off >= 0) p.cvec = cbase + op.cvec_off;
         mark();
-        hipError_t e = launch_conv(p, u->bf16, op.narrow, op.bn, st);
-        mark(); if (prof) ev_kind.push_back(0);
+        hipError_t e = op.flavor == 2 ? launch_conv_glds(p, op.narrow, op.bn, st) : launch_conv(p, u->bf16, op.narrow, op.bn, 0, st);
+        mark(); if (prof) { ev_kind.push_back(0); char tag[96]; snprintf(tag, sizeof tag, " [%dx%d k%d f%d bn%d wg%d ks%d]", p.H, p.W, p.kgroups, op.flavor, op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit); ev_label.push_back(op.label + tag); }
         if (e != hipSuccess) return fail(TD_ERR_HIP, "conv launch " + op.label + ": " + hipGetErrorString(e));
     }
     return TD_OK;
@@ -720,7 +740,18 @@ int td_engine_profile_read(td_engine* e, double* conv_ms, int64_t* conv_launches
     if (conv_launches) *conv_launches = e->prof_conv_launches;
     if (other_ms) *other_ms = e->prof_other_ms;
     if (other_launches) *other_launches = e->prof_other_launches;
-    if (reset) { e->prof_conv_ms = e->prof_other_ms = 0.0; e->prof_conv_launches = e->prof_other_launches = 0; }
+    if (reset) { e->prof_conv_ms = e->prof_other_ms = 0.0; e->prof_conv_launches = e->prof_other_launches = 0; e->prof_ops.clear(); }
+    return TD_OK;
+}
+int td_engine_profile_dump(td_engine* e, char* buf, int64_t capacity) {
+    std::string out;
+    for (auto& kv : e->prof_ops) {
+        char line[256];
+        snprintf(line, sizeof line, "%s\t%.4f\t%lld\n", kv.first.c_str(), kv.second.first, (long long)kv.second.second);
+        out += line;
+    }
+    if ((int64_t)out.size() + 1 > capacity) return fail(TD_ERR_ARG, "capacity");
+    memcpy(buf, out.c_str(), out.size() + 1);
     return TD_OK;
 }
 
@@ -791,9 +822,12 @@ int td_unet_forward(td_unet* u, int n, int H, int W, const float* x, const float
     } else {
         // rows = n "steps" x n tiles; sample i uses row i*n + i.  Build a compact [n][c_total] table by copying those rows to step 0's slot.
         if ((rc = compute_cvecs(u, *pl, ts, (const float*)dcond))) return rc;
-        for (int i = 1; i < n; ++i)
+        for (int i = 1; i < n; ++i) {
             HIP_TRY(hipMemcpyAsync((float*)pl->cvec->p + (size_t)i * u->c_total, (float*)pl->cvec->p + ((size_t)i * n + i) * u->c_total, (size_t)u->c_total * 4,
                                    hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync((float*)pl->emb->p + (size_t)i * u->emb_ch, (float*)pl->emb->p + ((size_t)i * n + i) * u->emb_ch, (size_t)u->emb_ch * 4,
+                                   hipMemcpyDeviceToDevice, st));
+        }
     }
     if (u->bf16) hipLaunchKernelGGL(prep_input_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)dx, (__bf16*)pl->xin, n, C, HW, u->chunk, 1.f);
     else hipLaunchKernelGGL(prep_input_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)dx, (float*)pl->xin, n, C, HW, u->chunk, 1.f);

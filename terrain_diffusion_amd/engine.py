@@ -29,6 +29,13 @@ class Engine:
         check(lib().td_engine_profile_read(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), int(reset)))
         return a.value, b.value, c.value, d.value
 
+    def profile_ops(self):
+        """[(label, ms, launches)] per fused op, accumulated in profile mode."""
+        buf = C.create_string_buffer(1 << 20)
+        check(lib().td_engine_profile_dump(self._h, buf, len(buf)))
+        rows = [l.split("\t") for l in buf.value.decode().splitlines() if l]
+        return [(r[0], float(r[1]), int(r[2])) for r in rows]
+
     @property
     def stream(self):
         return lib().td_engine_stream(self._h)

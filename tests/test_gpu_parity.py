@@ -264,3 +264,37 @@ def test_per_layer_activations_tiny(td, orc, golden):
         n += 1
     assert n == 21
     m.close()
+
+
+def test_unet_glds_flavour_forced(td, orc, golden):
+    """the LDS-DMA throughput kernel (normally chosen only for large pixel counts) forced onto every layer of the tiny models:
+    same bf16 tolerance vs the reference, and close to the register-staged flavour (same maths, different summation order)."""
+    from terrain_diffusion_amd.engine import get_engine
+    g = golden("unet")
+    eng = get_engine("cuda")
+    outs = {}
+    try:
+        for flavour, min_wgs in (("tap", 1 << 30), ("glds", 0)):
+            eng.set_option("glds_min_wgs", min_wgs)
+            cfg = orc["unet"].tiny_config(64, 1)
+            m = _model(td, orc, cfg, 77, "bf16")
+            x = torch.from_numpy(orc["rng"].standard_normal(7, (2, 5, 16, 16))).cuda()
+            y = m(x, torch.tensor([1.2, 0.3]), [torch.from_numpy(orc["rng"].standard_normal(8, (2, 58))).cuda()])
+            assert rel_rms(y.cpu().numpy(), g["tiny_out"]) < 2e-2, flavour
+            outs[flavour] = y.cpu().numpy()
+            m.close()
+            cfg2 = orc["unet"].tiny_config(64, 2, attn_resolutions=[128])
+            m2 = _model(td, orc, cfg2, 78, "bf16")
+            x2 = torch.from_numpy(orc["rng"].standard_normal(9, (3, 5, 32, 32))).cuda()   # batch 3: ragged image groups (4 images per narrow tile)
+            c2 = torch.from_numpy(orc["rng"].standard_normal(10, (1, 58))).expand(3, -1).contiguous().cuda()
+            y2 = m2(x2, torch.tensor([0.9, 0.9, 0.9]), [c2])
+            outs[flavour + "2"] = y2.cpu().numpy()
+            m2.close()
+    finally:
+        eng.set_option("glds_min_wgs", 192)
+    assert rel_rms(outs["glds"], outs["tap"]) < 1e-2
+    assert rel_rms(outs["glds2"], outs["tap2"]) < 1e-2
+    o2 = orc["unet"].OracleUnet(orc["unet"].tiny_config(64, 2, attn_resolutions=[128]), orc["unet"].synth_state_dict(orc["unet"].tiny_config(64, 2, attn_resolutions=[128]), seed=78))
+    x2 = torch.from_numpy(orc["rng"].standard_normal(9, (3, 5, 32, 32)))
+    ref = o2(x2, torch.tensor([0.9, 0.9, 0.9]), [torch.from_numpy(orc["rng"].standard_normal(10, (1, 58))).expand(3, -1)]).numpy()
+    assert rel_rms(outs["glds2"], ref) < 2e-2
