@@ -1,12 +1,14 @@
 #!/usr/bin/env python
 """Headline benchmark: decoded terrain megapixels / second at fixed steps (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W [--workload tile1|grid8] [--dtype bf16|fp32]
+    python bench.py --gpus N --steps K --warmup W [--workload tiles|grid8] [--tiles-per-step B] [--dtype bf16|fp32]
 
 A "step" is one pass of the hot path over one batch of synthetic input:
-  tile1 (default, BASELINE configs[1]): one 64x64-latent tile of the terrain-diffusion-30m base model through 20 EDM
-        DPM-Solver++ steps, including noise generation, conditioning, scheduler steps, blend + normalise.
-        0.262144 decoded MP per step.  N>1: every rank samples its own tile (independent objects -> weak scaling).
+  tiles (default, BASELINE configs[1]): a batch of B (default 64) INDEPENDENT single 64x64-latent tiles of the
+        terrain-diffusion-30m base model, each through 20 EDM DPM-Solver++ steps, including noise generation, scheduler steps,
+        pack/normalise.  Independent tiles are batched through the U-Net exactly as the reference batches latent tiles
+        (latents_batch_size, world_pipeline.py:292,326-330).  B x 0.262144 decoded MP per step.  The single-tile (B=1) latency
+        is reported alongside as "latency_single_tile_ms".  N>1: every rank samples its own batch (independent objects -> weak).
   grid8 (BASELINE configs[2]): an 8x8 grid of overlapping tiles (stride 32) on a 288x288 latent canvas, 20 steps,
         all 64 tiles batched per solver step, overlap blend at the end.  5.308416 decoded MP per step.
 Weights are synthetic (portable-RNG seeded, out_gain=1, emb_gain=0.5) and resident in HBM before the timed region; there
@@ -34,7 +36,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="tile1", choices=["tile1", "grid8"])
+    ap.add_argument("--workload", default="tiles", choices=["tiles", "grid8"])
+    ap.add_argument("--tiles-per-step", type=int, default=64)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--edm-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -56,28 +59,40 @@ def main():
 
     import terrain_diffusion_amd as td
     from terrain_diffusion_amd.engine import get_engine
-    from oracle import tiling
-    from oracle.unet import BASE_CONFIG, synth_state_dict
+    from terrain_diffusion_amd.synthetic import synthetic_state_dict, synthetic_cond_grid
+    from terrain_diffusion_amd.sampling import _tile_starts, _process_cond_img
+
+    # terrain-diffusion-30m base model (configs/diffusion_base/30m/diffusion_192-3.cfg:54-68)
+    BASE_CONFIG = dict(image_size=512, in_channels=5, out_channels=5, model_channels=192, model_channel_mults=[1, 2, 3, 4], layers_per_block=3,
+                       attn_resolutions=[8, 16], midblock_attention=True, concat_balance=0.5, conditional_inputs=[["tensor", 58, 1.0]], fourier_scale="pos")
 
     dev = f"cuda:{local_rank}"
     eng = get_engine(dev)
     cfg = dict(BASE_CONFIG)
-    sd = synth_state_dict(cfg, seed=1234)
-    model = td.EDMUnet2D(**cfg, dtype=args.dtype, device=dev).load_state_dict(sd)
+    model = td.EDMUnet2D(**cfg, dtype=args.dtype, device=dev)
+    model.load_state_dict(synthetic_state_dict(model, seed=1234))
     sch = td.EDMDPMSolverMultistepScheduler(sigma_min=0.002, sigma_max=80.0, sigma_data=0.5)
     E = args.edm_steps
-    if args.workload == "tile1":
+    if args.workload == "tiles":
         H = W = 64
-        tiles_per_step, mp_per_step = 1, (64 * 8) ** 2 / 1e6
+        tiles_per_step = args.tiles_per_step
+        mp_per_step = tiles_per_step * (64 * 8) ** 2 / 1e6
     else:
         H = W = 288
         tiles_per_step, mp_per_step = 64, (288 * 8) ** 2 / 1e6
-    nt = len(tiling.tile_starts(H, 64, 32))
-    cond = tiling.synthetic_cond_grid(nt, nt)
+    nt = len(_tile_starts(H, 64, 32))
+    cond = synthetic_cond_grid(nt, nt, device=dev)
     kw = dict(cond_means=torch.zeros(7), cond_stds=torch.ones(7), noise_level=torch.tensor(0.0), histogram_raw=torch.zeros(1, 5), steps=E, tile_size=64)
 
-    def one_step(i):
-        # a different canvas each step (noise origin moves), same as sampling successive regions of the world
+    cond58 = torch.cat([_process_cond_img(synthetic_cond_grid(1, 1, seed=0xC0DE + j, device=dev), torch.zeros(1, 5), torch.zeros(7), torch.ones(7), 0.0)
+                        for j in range(args.tiles_per_step)]) if args.workload == "tiles" else None
+
+    def one_step(i, b=None):
+        # different world regions each step (noise origins move), same as sampling successive regions of the world
+        if args.workload == "tiles":
+            b = b or tiles_per_step
+            origins = [(4096 * j, 4096 * i) for j in range(b)]
+            return td.sample_independent_tiles(model, sch, origins, cond58[:b], steps=E, noise_seed=42 + 5819 + rank)
         return td.sample_base_diffusion(model, sch, (1, 5, H, W), cond, noise_seed=42 + 5819 + rank, noise_origin=(0, 4096 * i), **kw)
 
     def sync():
@@ -110,8 +125,9 @@ def main():
         "metric": "terrain megapixels/sec (decoded) at fixed steps, 30m model", "value": round(value, 4), "unit": "MP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": ("BASELINE configs[1]: terrain-diffusion-30m base U-Net, single 64x64 latent tile, 20 EDM DPM-Solver++ steps"
-                                if args.workload == "tile1" else
+        "config": {"workload": (f"BASELINE configs[1]: terrain-diffusion-30m base U-Net, single 64x64 latent tile x 20 EDM DPM-Solver++ steps, "
+                                f"{tiles_per_step} independent tiles batched per step (reference latents_batch_size pattern)"
+                                if args.workload == "tiles" else
                                 "BASELINE configs[2]: terrain-diffusion-30m base U-Net, 8x8 tile grid (stride 32) with overlap blending, 20 steps"),
                    "tiles_per_step": tiles_per_step, "edm_steps": E, "decoded_mp_per_step": mp_per_step,
                    "parallelism": f"{world} independent tile streams (one process per GPU, no data-path collective)"},
@@ -137,18 +153,30 @@ def main():
             roof.update({"achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches_per_step": conv_n,
                          "avg_launch_us": round(avg_us, 3), "flop_per_launch": round(flop_per_launch),
                          "conv_kernel_ms_per_step": round(conv_ms, 3), "other_unet_kernel_ms_per_step": round(other_ms, 3)})
-            if tiles_per_step == 1 and args.dtype == "bf16":
+            if False:
                 gbs = E * WEIGHT_BYTES_BF16 / (conv_ms * 1e-3) / 1e9
                 roof["hbm_weight_stream"] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                                              "note": "weights read once per forward at batch 1 (algorithmic minimum bytes)"}
         else:
             roof.update({"achieved": roof["end_to_end_achieved"], "frac": roof["end_to_end_frac"]})
         result["roofline"] = roof
+        if args.workload == "tiles":
+            # secondary number: latency of ONE tile through the same path (batch 1: launch/HBM-latency bound, not MFMA bound)
+            one_step(20_000, 1); sync()
+            l0 = time.perf_counter()
+            for r_ in range(3):
+                one_step(20_001 + r_, 1)
+            sync()
+            lat = (time.perf_counter() - l0) / 3
+            result["latency_single_tile_ms"] = round(lat * 1e3, 3)
+            result["single_tile_mp_per_s"] = round(0.262144 / lat, 3)
 
         if world == 1 and not args.no_cpu_baseline:
             # CPU baseline = the oracle (CPU restatement pinned to the reference) on this host's cores, bounded sample
-            from oracle.unet import OracleUnet
-            om = OracleUnet(cfg, sd)
+            # (the only place bench.py touches oracle/: the checker is what is timed here, never the product path)
+            from oracle import tiling
+            from oracle.unet import OracleUnet, synth_state_dict
+            om = OracleUnet(cfg, synth_state_dict(cfg, seed=1234))
             ocond = tiling.synthetic_cond_grid(1, 1)
             run = lambda k: tiling.sample_base_diffusion_tiled(om, (1, 5, 64, 64), ocond, steps=k, tile_size=64)
             # pick the host thread count that is fastest for this workload (256 threads on the GPU node's host is ~150x slower
@@ -169,12 +197,12 @@ def main():
             run(n_sample_steps)
             cdt = time.perf_counter() - c0
             per_tile = cdt / n_sample_steps * E
-            overlap = 1.0 if args.workload == "tile1" else tiles_per_step * 0.262144 / mp_per_step
+            overlap = 1.0 if args.workload == "tiles" else tiles_per_step * 0.262144 / mp_per_step
             result["cpu_baseline"] = {"value": round(0.262144 / per_tile / overlap, 6), "unit": "MP/s", "cores": best_t, "kind": "port",
                                       "host_cpus": ncpu,
                                       "sample": f"oracle (torch fp32 CPU restatement pinned to the reference), 1 tile x {n_sample_steps} of {E} solver steps "
                                                 f"timed ({cdt:.1f} s on {best_t} threads, best of 8..128), scaled to {E} steps"
-                                                + ("" if args.workload == "tile1" else f" and to {tiles_per_step} overlapping tiles")}
+                                                + ("" if args.workload == "tiles" else f" and to {tiles_per_step} overlapping tiles")}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

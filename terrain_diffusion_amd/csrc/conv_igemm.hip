@@ -466,33 +466,45 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     }
 }
 
-// Split-K tail: sums the fp32 partial slabs in fixed order and applies the same epilogue. One wave per pixel.
+// Split-K tail: sums the fp32 partial slabs in fixed order (deterministic) and applies the same epilogue.
+// One wave per (pixel, 256-cout chunk); the K-split loop is unrolled 8-deep so the loads of a slab row are in flight together.
 template <typename T>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
     const int lane = threadIdx.x & 63;
     const size_t M = (size_t)p.N * p.H * p.W;
-    const size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pix >= M) return;
+    const int nchunks = (p.CoutPad + 255) / 256;
+    const size_t wid = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= M * nchunks) return;
+    const size_t pix = wid / nchunks;
+    const int chunk = (int)(wid % nchunks);
     const int x = (int)(pix % p.W), y = (int)((pix / p.W) % p.H), n = (int)(pix / ((size_t)p.W * p.H));
-    float rn = 1.f;
-    if (p.res_sumsq)
-        rn = pixel_rn(p.res_sumsq, p.res_nparts, (size_t)p.N * p.res_Hs * p.res_Ws, src_pixel(n, y, x, p.res_Hs, p.res_Ws, p.res_resample), p.res_inv_c);
+    const int co = chunk * 256 + lane * 4;
     float ss = 0.f;
-    for (int co = lane * 4; co < p.CoutPad; co += 256) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < p.ksplit; ++k) {
-            f32x4 t = *(const f32x4*)(p.partial + ((size_t)k * M + pix) * p.CoutPad + co);
-            v += t;
-        }
+    if (co < p.CoutPad) {
+        float rn = 1.f;
+        if (p.res_sumsq)
+            rn = pixel_rn(p.res_sumsq, p.res_nparts, (size_t)p.N * p.res_Hs * p.res_Ws, src_pixel(n, y, x, p.res_Hs, p.res_Ws, p.res_resample), p.res_inv_c);
         f32x4 aux = {0.f, 0.f, 0.f, 0.f};
         if (p.epi == EPI_EMB_SILU) aux = *(const f32x4*)(p.cvec + (size_t)n * p.cvec_stride + co);
         else if (p.epi == EPI_RESIDUAL && p.res) aux = load4<T>(p.res, (size_t)src_pixel(n, y, x, p.res_Hs, p.res_Ws, p.res_resample) * p.res_cstride + co);
-        ss += epilogue4<T>(p, n, y, x, co, v, rn, aux);
+        const float* base = p.partial + pix * p.CoutPad + co;
+        const size_t kstride = M * p.CoutPad;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= p.ksplit; k += 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(base + (size_t)(k + u) * kstride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        for (; k < p.ksplit; ++k) v += *(const f32x4*)(base + (size_t)k * kstride);
+        ss = epilogue4<T>(p, n, y, x, co, v, rn, aux);
     }
     if (p.out_sumsq) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
-        if (lane == 0) p.out_sumsq[pix] = ss;
+        if (lane == 0) p.out_sumsq[(size_t)chunk * M + pix] = ss;
     }
 }
 
@@ -512,8 +524,8 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (p.ksplit > 1) {
-        size_t M = (size_t)p.N * p.H * p.W;
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel<T>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, p);
+        size_t W_ = (size_t)p.N * p.H * p.W * ((p.CoutPad + 255) / 256);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel<T>, dim3((unsigned)((W_ + 3) / 4)), dim3(256), 0, st, p);
         e = hipGetLastError();
     }
     return e;

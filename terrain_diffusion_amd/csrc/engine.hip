@@ -451,7 +451,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
     const int chunk = u->chunk;
     const bool use_splitk = u->eng->option("splitk", 1) != 0;
     const int64_t splitk_target = u->eng->option("splitk_target_wgs", 512);
-    const int64_t bn128_min = u->eng->option("bn128_min_wgs", 1024);
+    const int64_t bn128_min = u->eng->option("bn128_min_wgs", 128);
     int rc;
     size_t partial_bytes = 0;
 
@@ -517,7 +517,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
             if (use_splitk && base < splitk_target / 2 && kgroups > 1) p.ksplit = (int)std::min<int64_t>(kgroups, (splitk_target + base - 1) / base);
         }
         p.epi = epi; p.out_f32 = out_f32 ? 1 : 0; p.clip = clip;
-        const int out_parts = p.ksplit > 1 ? 1 : p.n_ntiles * 2;
+        const int out_parts = p.ksplit > 1 ? (cw.cout_pad + 255) / 256 : p.n_ntiles * 2;
         if (out_f32) {
             outT->C = cw.cout; outT->cstride = 8; outT->H = h; outT->W = w; outT->sumsq = nullptr;
             if ((rc = new_buf(pl, (size_t)N * h * w * 8 * 4, &outT->ptr))) return rc;
@@ -855,7 +855,7 @@ int td_unet_read_activation(td_unet* u, int n, int H, int W, const char* label, 
     if (!strncmp(label, "sumsq:", 6)) {
         for (auto& op : pl->ops) {
             if (op.kind != Op::CONV || op.label != label + 6 || !op.p.out_sumsq) continue;
-            const int parts = op.p.ksplit > 1 ? 1 : op.p.n_ntiles * 2;
+            const int parts = op.p.ksplit > 1 ? (op.p.CoutPad + 255) / 256 : op.p.n_ntiles * 2;
             const size_t M = (size_t)n * op.out_H * op.out_W;
             dims[0] = parts; dims[1] = n; dims[2] = op.out_H; dims[3] = op.out_W;
             if ((int64_t)(parts * M) > capacity) return fail(TD_ERR_ARG, "capacity");

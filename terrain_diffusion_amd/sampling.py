@@ -137,6 +137,29 @@ def sample_base_diffusion(model, scheduler, shape, cond_inputs, *, cond_means, c
 
 
 @torch.no_grad()
+def sample_independent_tiles(model, scheduler, origins, cond, *, steps=20, tile_size=64, channels=5, noise_seed=42 + 5819, return_raw=False):
+    """A batch of INDEPENDENT single-tile jobs (BASELINE configs[1], batched the way the reference batches latent tiles with
+    `latents_batch_size`, world_pipeline.py:292,326-330): tile i = sample_base_diffusion(shape=(1,C,T,T), tile_size=T) at noise
+    origin origins[i] with conditioning vector cond[i] (n,58).  Every stage runs in the engine: noise field -> 20 x (U-Net +
+    DPM-Solver++ step) -> pack with the linear window / normalise / divide by sigma_data.  Returns (n, C, T, T) on the device."""
+    eng, dev = model.engine, model.device
+    sd = float(scheduler.config.sigma_data)
+    scheduler.set_timesteps(steps)
+    n = len(origins)
+    x = _noise.gaussian_noise_patches(noise_seed, origins, tile_size, tile_size, channels=channels, tile_h=64, tile_w=64,
+                                      scale=float(scheduler.sigmas[0]), device=dev)
+    cond = torch.as_tensor(cond, dtype=torch.float32).to(dev).contiguous()
+    sample_tiles_edm(model, scheduler, x, cond, steps)
+    if return_raw:
+        return x
+    # n single-window canvases stacked vertically: (C+1, n*T, T); same pack/normalise arithmetic as one canvas per tile
+    canvas = torch.empty((channels + 1, n * tile_size, tile_size), dtype=torch.float32, device=dev)
+    blend_windows(eng, canvas, x, [(i, 0) for i in range(n)], [i * tile_size for i in range(n)], [0], tile_size, accumulate=False)
+    out = blend_normalize(eng, canvas, 1.0 / sd)
+    return out.view(channels, n, tile_size, tile_size).permute(1, 0, 2, 3)
+
+
+@torch.no_grad()
 def sample_base_consistency(model, scheduler, shape, cond_inputs, *, cond_means, cond_stds, noise_level=0.0, histogram_raw, intermediate_t=0.0,
                             dtype=torch.float32, generator=None, tile_size=None, weight_window_fn=None, noise=None,
                             noise_seed=42 + 5819, noise_origin=(0, 0), max_batch=64):

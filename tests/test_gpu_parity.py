@@ -298,3 +298,31 @@ def test_unet_glds_flavour_forced(td, orc, golden):
     x2 = torch.from_numpy(orc["rng"].standard_normal(9, (3, 5, 32, 32)))
     ref = o2(x2, torch.tensor([0.9, 0.9, 0.9]), [torch.from_numpy(orc["rng"].standard_normal(10, (1, 58))).expand(3, -1)]).numpy()
     assert rel_rms(outs["glds2"], ref) < 2e-2
+
+
+def test_synthetic_weights_match_oracle_recipe(td, orc):
+    """the product's GPU-generated synthetic weights equal the oracle's CPU recipe (<= 1 ulp on normals)."""
+    from terrain_diffusion_amd.synthetic import synthetic_state_dict, synthetic_cond_grid
+    cfg = orc["unet"].tiny_config(64, 1)
+    m = td.EDMUnet2D(**cfg, dtype="bf16")
+    a = synthetic_state_dict(m, seed=77)
+    b = orc["unet"].synth_state_dict(cfg, seed=77)
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.allclose(a[k].float(), b[k].float(), rtol=2e-7, atol=0), k
+    assert torch.allclose(synthetic_cond_grid(2, 3), orc["tiling"].synthetic_cond_grid(2, 3), rtol=2e-7, atol=0)
+    m.close()
+
+
+def test_independent_tiles_batch(td, orc, golden, base_models):
+    """a batch of independent single tiles == the single-tile sampler run one at a time (bf16; tile 0 vs the reference golden)."""
+    from oracle import tiling
+    g = golden("sampling")
+    sch = td.EDMDPMSolverMultistepScheduler()
+    c0 = tiling.process_cond_img(tiling.synthetic_cond_grid(1, 1), torch.zeros(1, 5), torch.zeros(7), torch.ones(7), 0.0)
+    c1 = tiling.process_cond_img(tiling.synthetic_cond_grid(1, 1, seed=5), torch.zeros(1, 5), torch.zeros(7), torch.ones(7), 0.0)
+    out = td.sample_independent_tiles(base_models["bf16"], sch, [(0, 0), (4096, -640)], torch.cat([c0, c1]), steps=20)
+    assert out.shape == (2, 5, 64, 64)
+    assert rel_rms(out[0:1].cpu().numpy(), g["base_tile_steps20"]) < 2e-2
+    solo = td.sample_independent_tiles(base_models["bf16"], sch, [(4096, -640)], c1, steps=20)
+    assert rel_rms(solo.cpu().numpy(), out[1:2].cpu().numpy()) < 2e-2   # different kernel flavours/tiles at batch 1 vs 2: same maths
