@@ -437,7 +437,8 @@ struct SegSpec { const Tensor* t; int C; int taps; int resample; int xform; floa
 
 static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
     char key[64];
-    snprintf(key, sizeof key, "%d_%d_%d", N, H, W);
+    snprintf(key, sizeof key, "%d_%d_%d_%d%d%d_%lld", N, H, W, (int)u->eng->option("batch_invariant", 0), (int)u->eng->option("glds", 1),
+             (int)u->eng->option("splitk", 1), (long long)u->eng->option("glds_min_wgs", 192));
     auto it = u->plans.find(key);
     if (it != u->plans.end()) { *out = it->second.get(); return TD_OK; }
     if (N < 1 || N > 1023 || H > 1023 || W > 1023) return fail(TD_ERR_ARG, "batch/size out of range");
@@ -498,7 +499,10 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
             const int TH2 = op.narrow ? 8 : 16, TW2 = op.narrow ? 8 : 16, NIMG2 = op.narrow ? 4 : 1;
             const int bn2 = cw.cout_pad % 128 == 0 ? 128 : (cw.cout_pad % 96 == 0 ? 96 : 0);
             const int64_t mt2 = (int64_t)((w + TW2 - 1) / TW2) * ((h + TH2 - 1) / TH2) * ((N + NIMG2 - 1) / NIMG2);
-            if (u->bf16 && bn2 && u->eng->option("glds", 1) && mt2 * (cw.cout_pad / bn2) >= u->eng->option("glds_min_wgs", 192)) {
+            // "batch_invariant": kernel flavour and K order do not depend on the batch size (no split-K, LDS-DMA flavour whenever it
+            // applies), so a window's result is bit-identical whatever other windows share its batch / GPU.
+            const bool inv = u->eng->option("batch_invariant", 0) != 0;
+            if (u->bf16 && bn2 && u->eng->option("glds", 1) && (inv || mt2 * (cw.cout_pad / bn2) >= u->eng->option("glds_min_wgs", 192))) {
                 op.flavor = 2; op.bn = bn2;
                 p.tiles_x = (w + TW2 - 1) / TW2; p.tiles_y = (h + TH2 - 1) / TH2; p.img_groups = (N + NIMG2 - 1) / NIMG2;
                 p.n_ntiles = cw.cout_pad / bn2; p.ksplit = 1;
@@ -514,7 +518,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
             p.n_ntiles = cw.cout_pad / op.bn;
             const int64_t base = mt * p.n_ntiles;
             p.ksplit = 1;
-            if (use_splitk && base < splitk_target / 2 && kgroups > 1) p.ksplit = (int)std::min<int64_t>(kgroups, (splitk_target + base - 1) / base);
+            if (use_splitk && !u->eng->option("batch_invariant", 0) && base < splitk_target / 2 && kgroups > 1) p.ksplit = (int)std::min<int64_t>(kgroups, (splitk_target + base - 1) / base);
         }
         p.epi = epi; p.out_f32 = out_f32 ? 1 : 0; p.clip = clip;
         const int out_parts = p.ksplit > 1 ? (cw.cout_pad + 255) / 256 : p.n_ntiles * 2;
@@ -987,7 +991,7 @@ int td_sample_edm(td_unet* u, int n, int H, int W, int n_steps, const float* sig
         HIP_TRY(hipGraphLaunch(pl->graph, st));
     } else if ((rc = enqueue())) return rc;
     HIP_TRY(hipMemcpyAsync(x, pl->x->p, xbytes, x_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
-    if (!x_dev) HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipStreamSynchronize(st));  // the caller's framework uses other streams: results must be complete on return
     return TD_OK;
 }
 

@@ -1,0 +1,187 @@
+"""Sharding of the tiled sampler across the GPUs of one node (one process per GPU, torch.distributed: RCCL on GPUs, gloo in tests).
+
+The reference is single-process; its scaling mechanism is the algorithm itself: inside a phase every window is independent
+(docs/index.html "Embarrassingly parallel"), and between phases / at the final blend a canvas pixel needs the windows that
+overlap it (sample_diffusion_base.py:164-168).  So:
+
+  * the window grid is cut into a 2-D block mesh, one block per rank; a rank samples only its own windows;
+  * each rank OWNS the canvas region that starts at its first window's origin (up to the next block's first origin);
+  * seam exchange: a rank sends the raw outputs of the windows that reach into a neighbour's region (its last window row /
+    column / corner) to that neighbour — point-to-point isend/irecv over xGMI, ~80 KB per window, no all-reduce;
+  * every rank blends its own region with the deterministic gather kernel in ascending (row, col) window order — the
+    reference's loop order — so the result is bit-identical to the single-GPU result when the engine runs in batch-invariant
+    mode (fixed kernel flavour, no split-K), and within fp32/bf16 rounding otherwise.
+Exchanging window outputs instead of partial accumulator strips costs ~2.5x the bytes (still KBs) and buys a
+canonical summation order independent of the GPU count.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def _tile_starts(length, tile_size, stride):
+    if length <= tile_size:
+        return [0]
+    starts = list(range(0, max(1, length - tile_size + 1), max(1, stride)))
+    if starts[-1] != length - tile_size:
+        starts.append(length - tile_size)
+    return starts
+
+
+def mesh_shape(world, n_rows, n_cols):
+    """(pr, pc) with pr*pc == world, blocks as square as possible, never more parts than windows along an axis."""
+    best = None
+    for pr in range(1, world + 1):
+        if world % pr:
+            continue
+        pc = world // pr
+        if pr > n_rows or pc > n_cols:
+            continue
+        score = abs(math.log((n_rows / pr) / (n_cols / pc)))
+        if best is None or score < best[0]:
+            best = (score, pr, pc)
+    if best is None:
+        raise ValueError(f"cannot place {world} ranks on a {n_rows}x{n_cols} window grid")
+    return best[1], best[2]
+
+
+def _cuts(n, parts):
+    return [(i * n) // parts for i in range(parts + 1)]
+
+
+class ShardPlan:
+    """Static description of who samples which window, who owns which canvas region and which window outputs cross seams."""
+
+    def __init__(self, H, W, tile_size, world, stride=None):
+        self.H, self.W, self.size, self.world = H, W, tile_size, world
+        stride = stride or tile_size // 2
+        self.h_starts, self.w_starts = _tile_starts(H, tile_size, stride), _tile_starts(W, tile_size, stride)
+        nr, nc = len(self.h_starts), len(self.w_starts)
+        self.pr, self.pc = mesh_shape(world, nr, nc)
+        self.row_cuts, self.col_cuts = _cuts(nr, self.pr), _cuts(nc, self.pc)
+        self.owner = {}
+        self.windows = [[] for _ in range(world)]
+        for br in range(self.pr):
+            for bc in range(self.pc):
+                r = br * self.pc + bc
+                for ic in range(self.row_cuts[br], self.row_cuts[br + 1]):
+                    for jc in range(self.col_cuts[bc], self.col_cuts[bc + 1]):
+                        self.owner[(ic, jc)] = r
+                        self.windows[r].append((ic, jc))
+        # owned canvas regions: from the origin of the block's first window to the origin of the next block's first window
+        self.regions = []
+        for br in range(self.pr):
+            for bc in range(self.pc):
+                y0 = self.h_starts[self.row_cuts[br]] if br > 0 else 0
+                y1 = self.h_starts[self.row_cuts[br + 1]] if br + 1 < self.pr else H
+                x0 = self.w_starts[self.col_cuts[bc]] if bc > 0 else 0
+                x1 = self.w_starts[self.col_cuts[bc + 1]] if bc + 1 < self.pc else W
+                self.regions.append((y0, y1, x0, x1))
+        # windows intersecting each region, and the seam traffic (src -> dst: windows of src that dst's region needs)
+        self.needed = []
+        for r, (y0, y1, x0, x1) in enumerate(self.regions):
+            need = [(ic, jc) for ic, hs in enumerate(self.h_starts) for jc, ws in enumerate(self.w_starts)
+                    if hs < y1 and hs + tile_size > y0 and ws < x1 and ws + tile_size > x0]
+            self.needed.append(need)
+        self.sends = {(s, d): [w for w in self.needed[d] if self.owner[w] == s] for s in range(world) for d in range(world) if s != d}
+        self.sends = {k: v for k, v in self.sends.items() if v}
+
+    def seam_bytes(self, channels=5):
+        return {k: len(v) * channels * self.size * self.size * 4 for k, v in self.sends.items()}
+
+
+def exchange_windows(plan: ShardPlan, rank, my_tiles, group=None):
+    """my_tiles: [len(plan.windows[rank]), C, S, S] outputs of this rank's windows (device of the backend).  Returns
+    {(ic, jc): tile} for every window this rank's region needs (local ones included)."""
+    local_index = {w: i for i, w in enumerate(plan.windows[rank])}
+    have = {w: my_tiles[local_index[w]] for w in plan.needed[rank] if plan.owner[w] == rank}
+    ops, recv_bufs = [], {}
+    for (s, d), wins in sorted(plan.sends.items()):
+        if s == rank:
+            buf = torch.stack([my_tiles[local_index[w]] for w in wins]).contiguous()
+            ops.append(dist.P2POp(dist.isend, buf, d, group))
+        elif d == rank:
+            buf = torch.empty((len(wins),) + tuple(my_tiles.shape[1:]), dtype=my_tiles.dtype, device=my_tiles.device)
+            recv_bufs[s] = (buf, wins)
+            ops.append(dist.P2POp(dist.irecv, buf, s, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for s, (buf, wins) in recv_bufs.items():
+        for i, w in enumerate(wins):
+            have[w] = buf[i]
+    return have
+
+
+def blend_region(plan: ShardPlan, rank, have, blend_fn, normalize_fn, channels, scale):
+    """Blends this rank's owned canvas region from the window outputs in `have` (ascending window order) -> (C, h, w)."""
+    y0, y1, x0, x1 = plan.regions[rank]
+    wins = sorted(have)
+    tiles = torch.stack([have[w] for w in wins]).contiguous()
+    canvas = torch.zeros((channels + 1, y1 - y0, x1 - x0), dtype=torch.float32, device=tiles.device)
+    blend_fn(canvas, tiles, wins, [h - y0 for h in plan.h_starts], [w - x0 for w in plan.w_starts], plan.size)
+    return normalize_fn(canvas, scale)
+
+
+def engine_fns(model, scheduler, plan, cond_inputs, *, cond_means, cond_stds, noise_level, histogram_raw, steps, channels, noise_seed, noise_origin,
+               max_batch):
+    """(sample_fn, blend_fn, normalize_fn) backed by the HIP engine."""
+    from . import sampling as _s
+
+    def sample_fn(windows):
+        outs = []
+        cond = torch.as_tensor(cond_inputs, dtype=torch.float32)
+        for b0 in range(0, len(windows), max_batch):
+            chunk = windows[b0:b0 + max_batch]
+            origins = [(noise_origin[0] + plan.h_starts[ic], noise_origin[1] + plan.w_starts[jc]) for ic, jc in chunk]
+            c58 = _s._tile_conditioning(cond, chunk, histogram_raw, cond_means, cond_stds, noise_level)
+            outs.append(_s.sample_independent_tiles(model, scheduler, origins, c58, steps=steps, tile_size=plan.size, channels=channels,
+                                                    noise_seed=noise_seed, return_raw=True))
+        return torch.cat(outs)
+
+    def blend_fn(canvas, tiles, wins, hs, ws, size):
+        _s.blend_windows(model.engine, canvas, tiles, wins, hs, ws, size, accumulate=False)
+
+    def normalize_fn(canvas, scale):
+        return _s.blend_normalize(model.engine, canvas, scale)
+
+    return sample_fn, blend_fn, normalize_fn
+
+
+def sample_base_diffusion_sharded(model, scheduler, shape, cond_inputs, *, cond_means, cond_stds, noise_level=0.0, histogram_raw, steps=15,
+                                  tile_size=64, noise_seed=42 + 5819, noise_origin=(0, 0), max_batch=64, group=None, gather_to=None,
+                                  sample_fn=None, blend_fn=None, normalize_fn=None):
+    """Sharded sample_base_diffusion (terrain_diffusion/training/evaluation/sample_diffusion_base.py:115-168).
+    Returns (region_tensor (C,h,w), (y0,y1,x0,x1)) for this rank, or the assembled (1,C,H,W) on rank `gather_to`.
+    sample_fn / blend_fn / normalize_fn default to the HIP engine; tests inject CPU stand-ins to exercise the plumbing under gloo."""
+    B, C_, H, W = shape
+    assert B == 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    plan = ShardPlan(H, W, tile_size, world)
+    sd = float(scheduler.config.sigma_data)
+    if sample_fn is None:
+        sample_fn, blend_fn, normalize_fn = engine_fns(model, scheduler, plan, cond_inputs, cond_means=cond_means, cond_stds=cond_stds, noise_level=noise_level,
+                                                       histogram_raw=histogram_raw, steps=steps, channels=C_, noise_seed=noise_seed, noise_origin=noise_origin,
+                                                       max_batch=max_batch)
+    my_tiles = sample_fn(plan.windows[rank])
+    have = exchange_windows(plan, rank, my_tiles, group) if world > 1 else {w: my_tiles[i] for i, w in enumerate(plan.windows[rank])}
+    region = blend_region(plan, rank, have, blend_fn, normalize_fn, C_, 1.0 / sd)
+    if gather_to is None:
+        return region, plan.regions[rank]
+    if world == 1:
+        return region[None]
+    # assemble on one rank (optional; production keeps the canvas sharded like the reference keeps tiles in a tile store)
+    if rank == gather_to:
+        full = torch.empty((C_, H, W), dtype=torch.float32, device=region.device)
+        for r, (y0, y1, x0, x1) in enumerate(plan.regions):
+            if r == rank:
+                full[:, y0:y1, x0:x1] = region
+            else:
+                buf = torch.empty((C_, y1 - y0, x1 - x0), dtype=torch.float32, device=region.device)
+                dist.recv(buf, r, group)
+                full[:, y0:y1, x0:x1] = buf
+        return full[None]
+    dist.send(region.contiguous(), gather_to, group)
+    return None

@@ -326,3 +326,37 @@ def test_independent_tiles_batch(td, orc, golden, base_models):
     assert rel_rms(out[0:1].cpu().numpy(), g["base_tile_steps20"]) < 2e-2
     solo = td.sample_independent_tiles(base_models["bf16"], sch, [(4096, -640)], c1, steps=20)
     assert rel_rms(solo.cpu().numpy(), out[1:2].cpu().numpy()) < 2e-2   # different kernel flavours/tiles at batch 1 vs 2: same maths
+
+
+def test_sharded_sampling_simulated_ranks(td, orc):
+    """2 and 4 'ranks' simulated on one GPU (same plan / seam lists / regional blend as the RCCL path, exchange done in memory):
+    with the engine in batch-invariant mode the assembled canvas is BIT-identical to the unsharded sampler."""
+    from terrain_diffusion_amd.engine import get_engine
+    from terrain_diffusion_amd.parallel import ShardPlan, engine_fns, blend_region
+    from oracle import tiling
+    eng = get_engine("cuda")
+    eng.set_option("batch_invariant", 1)
+    try:
+        cfg = orc["unet"].tiny_config(64, 1)
+        m = _model(td, orc, cfg, 77, "bf16")
+        sch = td.EDMDPMSolverMultistepScheduler()
+        H, W, S, steps = 40, 56, 16, 5
+        cond = tiling.synthetic_cond_grid(len(tiling.tile_starts(H, S, S // 2)), len(tiling.tile_starts(W, S, S // 2)))
+        kw = dict(cond_means=torch.zeros(7), cond_stds=torch.ones(7), noise_level=torch.tensor(0.0), histogram_raw=torch.zeros(1, 5))
+        ref = td.sample_base_diffusion(m, sch, (1, 5, H, W), cond, steps=steps, tile_size=S, noise_seed=7, **kw)
+        for world in (2, 4):
+            plan = ShardPlan(H, W, S, world)
+            fns = engine_fns(m, sch, plan, cond, steps=steps, channels=5, noise_seed=7, noise_origin=(0, 0), max_batch=64, **kw)
+            tiles = [fns[0](plan.windows[r]) for r in range(world)]
+            full = torch.empty((5, H, W), device="cuda")
+            for r in range(world):
+                have = {}
+                for w_ in plan.needed[r]:
+                    o = plan.owner[w_]
+                    have[w_] = tiles[o][plan.windows[o].index(w_)]
+                y0, y1, x0, x1 = plan.regions[r]
+                full[:, y0:y1, x0:x1] = blend_region(plan, r, have, fns[1], fns[2], 5, 1.0 / 0.5)
+            assert torch.equal(full[None], ref), world
+        m.close()
+    finally:
+        eng.set_option("batch_invariant", 0)
