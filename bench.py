@@ -9,6 +9,9 @@ A "step" is one pass of the hot path over one batch of synthetic input:
         pack/normalise.  Independent tiles are batched through the U-Net exactly as the reference batches latent tiles
         (latents_batch_size, world_pipeline.py:292,326-330).  B x 0.262144 decoded MP per step.  The single-tile (B=1) latency
         is reported alongside as "latency_single_tile_ms".  N>1: every rank samples its own batch (independent objects -> weak).
+  grid32 (BASELINE configs[3]): ONE 32x32 tile grid (1056x1056 latent canvas, 71.37 decoded MP) sharded over the N ranks as a
+        2-D block mesh with a point-to-point seam exchange of window outputs over RCCL (terrain_diffusion_amd/parallel.py);
+        "scaling": "strong".
   grid8 (BASELINE configs[2]): an 8x8 grid of overlapping tiles (stride 32) on a 288x288 latent canvas, 20 steps,
         all 64 tiles batched per solver step, overlap blend at the end.  5.308416 decoded MP per step.
 Weights are synthetic (portable-RNG seeded, out_gain=1, emb_gain=0.5) and resident in HBM before the timed region; there
@@ -36,7 +39,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="tiles", choices=["tiles", "grid8"])
+    ap.add_argument("--workload", default="tiles", choices=["tiles", "grid8", "grid32"])
     ap.add_argument("--tiles-per-step", type=int, default=64)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--edm-steps", type=int, default=20)
@@ -77,6 +80,9 @@ def main():
         H = W = 64
         tiles_per_step = args.tiles_per_step
         mp_per_step = tiles_per_step * (64 * 8) ** 2 / 1e6
+    elif args.workload == "grid32":
+        H = W = 1056
+        tiles_per_step, mp_per_step = 1024, (1056 * 8) ** 2 / 1e6
     else:
         H = W = 288
         tiles_per_step, mp_per_step = 64, (288 * 8) ** 2 / 1e6
@@ -93,6 +99,9 @@ def main():
             b = b or tiles_per_step
             origins = [(4096 * j, 4096 * i) for j in range(b)]
             return td.sample_independent_tiles(model, sch, origins, cond58[:b], steps=E, noise_seed=42 + 5819 + rank)
+        if args.workload == "grid32":
+            from terrain_diffusion_amd.parallel import sample_base_diffusion_sharded
+            return sample_base_diffusion_sharded(model, sch, (1, 5, H, W), cond, noise_seed=42 + 5819, noise_origin=(0, 4096 * i), max_batch=64, **kw)[0]
         return td.sample_base_diffusion(model, sch, (1, 5, H, W), cond, noise_seed=42 + 5819 + rank, noise_origin=(0, 4096 * i), **kw)
 
     def sync():
@@ -119,15 +128,18 @@ def main():
         dt = float(tt.item())
     assert bool(torch.isfinite(out).all())
     ms_per_step = dt / args.steps * 1e3
-    value = world * args.steps * mp_per_step / dt
+    strong = args.workload == "grid32"
+    value = (1 if strong else world) * args.steps * mp_per_step / dt
 
     result = {
         "metric": "terrain megapixels/sec (decoded) at fixed steps, 30m model", "value": round(value, 4), "unit": "MP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": (f"BASELINE configs[1]: terrain-diffusion-30m base U-Net, single 64x64 latent tile x 20 EDM DPM-Solver++ steps, "
                                 f"{tiles_per_step} independent tiles batched per step (reference latents_batch_size pattern)"
                                 if args.workload == "tiles" else
+                                "BASELINE configs[3]: terrain-diffusion-30m base U-Net, 32x32 tile grid sharded over the ranks, seam exchange over RCCL, 20 steps"
+                                if args.workload == "grid32" else
                                 "BASELINE configs[2]: terrain-diffusion-30m base U-Net, 8x8 tile grid (stride 32) with overlap blending, 20 steps"),
                    "tiles_per_step": tiles_per_step, "edm_steps": E, "decoded_mp_per_step": mp_per_step,
                    "parallelism": f"{world} independent tile streams (one process per GPU, no data-path collective)"},
@@ -135,7 +147,7 @@ def main():
 
     if rank == 0:
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        flop_per_step = tiles_per_step * E * GFLOP_PER_FORWARD * 1e9
+        flop_per_step = tiles_per_step * E * GFLOP_PER_FORWARD * 1e9 / (world if strong else 1)  # per GPU
         e2e_tflops = flop_per_step / (ms_per_step * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "td::conv_igemm_kernel", "peak": peak, "unit": "TFLOP/s", "traffic": None,
                 "end_to_end_achieved": round(e2e_tflops, 2), "end_to_end_frac": round(e2e_tflops / peak, 4)}

@@ -10,7 +10,9 @@
  * td_last_error().  One engine per GPU, single caller thread per handle (the reference's servers run
  * threaded=False: terrain_diffusion/inference/api.py:249).  Tensor arguments are raw pointers; unless a
  * parameter says "host", a pointer may be device OR host memory (detected with hipPointerGetAttributes;
- * host buffers are staged through the engine's stream).  All tensors are fp32 in the reference's layouts
+ * host buffers are staged through the engine's stream).  Stream contract: the engine works on its own non-blocking HIP stream;
+ * device buffers passed in must be complete before the call (synchronise the producing stream) and every result is complete when
+ * the call returns.  All tensors are fp32 in the reference's layouts
  * (NCHW tiles, (C+1,H,W) canvases); bf16 exists only inside the engine.
  */
 #ifndef TD_ENGINE_H

@@ -63,13 +63,18 @@ def get_engine(device=None) -> Engine:
 
 
 def ptr(t):
-    """raw pointer of a contiguous fp32 torch tensor / numpy array (host or device), or None."""
+    """raw pointer of a contiguous fp32 torch tensor / numpy array (host or device), or None.
+    C-ABI contract: device buffers handed to the engine must be COMPLETE (the engine launches on its own non-blocking stream and
+    does not know the caller's streams) and results are complete on return.  Torch produces tensors asynchronously on its current
+    stream (uploads, stack/clone/contiguous), so a device pointer is only taken after that stream has been synchronised."""
     if t is None:
         return None
     if isinstance(t, np.ndarray):
         assert t.flags["C_CONTIGUOUS"]
         return C.c_void_p(t.ctypes.data)
     assert t.is_contiguous()
+    if t.is_cuda:
+        torch.cuda.current_stream(t.device).synchronize()
     return C.c_void_p(t.data_ptr())
 
 

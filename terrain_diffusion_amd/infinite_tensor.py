@@ -1,0 +1,194 @@
+"""Operator surface the hot path sits behind: InfiniteTensor / TensorWindow / MemoryTileStore / HDF5TileStore.
+
+The reference imports these from the third-party package `infinite-tensor>=0.3.0` (requirements.txt:32), which is neither vendored
+nor installable offline, so its behaviour is pinned ONLY by the reference's call sites ("parity unpinned"):
+  annotated_infinite_panorama.py:153-228, terrain_diffusion/inference/world_pipeline.py:669-674, 982-992, 1146-1201, 1259-1270.
+Semantics implemented here (and tested against explicit window sums):
+  * window k along a dim covers [k*stride + offset, k*stride + offset + size); dims whose shape entry is None are unbounded in
+    both directions (negative indices allowed), other dims are [0, shape);
+  * tensor[slices] = SUM over all windows intersecting the region of f(ctx, *arg_slices) restricted to the region, summed in
+    ascending window-index order (deterministic);
+  * arg_slices[i] for output window ctx = args[i] sliced by args_windows[i] at the SAME index ctx (un-normalised (C+1,...) sums:
+    callers divide by the weight channel themselves, world_pipeline.py:1078,1080,1223);
+  * with batch_size set, f receives lists: f(ctxs, *lists_of_arg_slices) -> list of outputs, at most batch_size per call — this is
+    where the engine batches all missing windows of a phase through the U-Net;
+  * window outputs are cached in a tile store (LRU by bytes); evicted windows are recomputed identically (everything upstream is
+    seed-deterministic), which is what makes "streaming tile eviction" safe.
+Host-side plumbing only: the arithmetic inside f runs in the HIP engine.
+"""
+import itertools
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+
+class TensorWindow:
+    def __init__(self, size, stride=None, offset=None):
+        self.size = tuple(int(s) for s in size)
+        self.stride = tuple(int(s) for s in (stride if stride is not None else size))
+        self.offset = tuple(int(o) for o in (offset if offset is not None else (0,) * len(self.size)))
+        assert len(self.size) == len(self.stride) == len(self.offset)
+
+    def bounds(self, ctx):
+        """[(lo, hi)] of window index tuple ctx."""
+        return [(k * st + of, k * st + of + sz) for k, sz, st, of in zip(ctx, self.size, self.stride, self.offset)]
+
+    def indices_intersecting(self, lo, hi, d):
+        """window indices k along dim d whose extent intersects [lo, hi)."""
+        sz, st, of = self.size[d], self.stride[d], self.offset[d]
+        k_min = -((-(lo - of - sz + 1)) // st)          # ceil((lo - of - sz + 1) / st)
+        k_max = (hi - 1 - of) // st
+        return range(k_min, k_max + 1)
+
+
+class MemoryTileStore:
+    """LRU cache of window outputs, bounded in bytes (world_pipeline.py:669: MemoryTileStore(cache_size_bytes=...))."""
+
+    def __init__(self, cache_size_bytes=100 * 2 ** 20):
+        self.cache_size_bytes = cache_size_bytes
+        self._d = OrderedDict()
+        self._bytes = 0
+        self.hits = self.misses = self.evictions = 0
+
+    def get(self, key):
+        t = self._d.get(key)
+        if t is None:
+            self.misses += 1
+            return None
+        self._d.move_to_end(key)
+        self.hits += 1
+        return t
+
+    def put(self, key, t):
+        nb = t.numel() * t.element_size()
+        old = self._d.pop(key, None)
+        if old is not None:
+            self._bytes -= old.numel() * old.element_size()
+        self._d[key] = t
+        self._bytes += nb
+        while self.cache_size_bytes is not None and self._bytes > self.cache_size_bytes and len(self._d) > 1:
+            _, ev = self._d.popitem(last=False)
+            self._bytes -= ev.numel() * ev.element_size()
+            self.evictions += 1
+
+    def clear(self, tensor_id=None):
+        if tensor_id is None:
+            self._d.clear()
+            self._bytes = 0
+            return
+        for k in [k for k in self._d if k[0] == tensor_id]:
+            t = self._d.pop(k)
+            self._bytes -= t.numel() * t.element_size()
+
+    def close(self):
+        self.clear()
+
+
+class HDF5TileStore(MemoryTileStore):
+    """Persistent world cache of the reference (world_pipeline.py:671-674).  h5py is not available in this environment; the
+    persistent format is listed as a "next" row in SURVEY.md §8f-3."""
+
+    def __init__(self, path, mode="a", compression="gzip", compression_opts=4, cache_size_tiles=100):
+        try:
+            import h5py  # noqa: F401
+        except ImportError as e:
+            raise ImportError("HDF5TileStore needs h5py, which is not installed here; use MemoryTileStore") from e
+        raise NotImplementedError("HDF5 persistence is a 'next' row (SURVEY.md §8f-3)")
+
+
+class InfiniteTensor:
+    def __init__(self, shape, f, output_window, args=(), args_windows=(), tile_store=None, tensor_id=None, batch_size=None, dtype=torch.float32):
+        self.shape = tuple(shape)
+        self.f = f
+        self.output_window = output_window
+        self.args = tuple(args)
+        self.args_windows = tuple(args_windows)
+        assert len(self.args) == len(self.args_windows)
+        assert len(output_window.size) == len(self.shape)
+        self.tile_store = tile_store if tile_store is not None else MemoryTileStore()
+        self.tensor_id = tensor_id if tensor_id is not None else f"tensor{id(self)}"
+        self.batch_size = batch_size
+        self.dtype = dtype
+
+    # ------------------------------------------------------------------ region bookkeeping
+    def _normalize_slices(self, idx):
+        if not isinstance(idx, tuple):
+            idx = (idx,)
+        idx = list(idx) + [slice(None)] * (len(self.shape) - len(idx))
+        lo, hi, squeeze = [], [], []
+        for d, (s, n) in enumerate(zip(idx, self.shape)):
+            if isinstance(s, (int, np.integer)):
+                a, b = int(s), int(s) + 1
+                squeeze.append(d)
+            else:
+                if s.step not in (None, 1):
+                    raise IndexError("strided slicing is not supported")
+                if n is None:
+                    if s.start is None or s.stop is None:
+                        raise IndexError(f"dim {d} is unbounded: give explicit start and stop")
+                    a, b = int(s.start), int(s.stop)
+                else:
+                    a, b, _ = s.indices(n)
+            if n is not None and (a < 0 or b > n):
+                raise IndexError(f"index out of range on bounded dim {d}")
+            lo.append(a)
+            hi.append(b)
+        return lo, hi, squeeze
+
+    def _windows_for(self, lo, hi):
+        ranges = [self.output_window.indices_intersecting(lo[d], hi[d], d) for d in range(len(self.shape))]
+        return list(itertools.product(*ranges))
+
+    # ------------------------------------------------------------------ evaluation
+    def _ensure(self, ctxs):
+        """Computes (batched) every window of `ctxs` that is not cached; returns {ctx: output}."""
+        out, missing = {}, []
+        for c in ctxs:
+            t = self.tile_store.get((self.tensor_id, c))
+            if t is None:
+                missing.append(c)
+            else:
+                out[c] = t
+        if missing:
+            bs = self.batch_size or 1
+            for b0 in range(0, len(missing), bs if self.batch_size else 1):
+                chunk = missing[b0:b0 + (bs if self.batch_size else 1)]
+                arg_lists = []
+                for a, aw in zip(self.args, self.args_windows):
+                    sl = []
+                    for c in chunk:
+                        b = aw.bounds(c)
+                        sl.append(a[tuple(slice(l, h) for l, h in b)])
+                    arg_lists.append(sl)
+                if self.batch_size:
+                    res = self.f(list(chunk), *arg_lists)
+                else:
+                    res = [self.f(chunk[0], *[al[0] for al in arg_lists])]
+                assert len(res) == len(chunk)
+                for c, r in zip(chunk, res):
+                    r = torch.as_tensor(r, dtype=self.dtype).detach().cpu()
+                    assert tuple(r.shape) == self.output_window.size, f"f returned {tuple(r.shape)}, window is {self.output_window.size}"
+                    self.tile_store.put((self.tensor_id, c), r)
+                    out[c] = r
+        return out
+
+    def __getitem__(self, idx):
+        lo, hi, squeeze = self._normalize_slices(idx)
+        ctxs = sorted(self._windows_for(lo, hi))
+        tiles = self._ensure(ctxs)
+        region = torch.zeros([h - l for l, h in zip(lo, hi)], dtype=self.dtype)
+        for c in ctxs:
+            b = self.output_window.bounds(c)
+            src, dst = [], []
+            for d, (wl, wh) in enumerate(b):
+                a, e = max(wl, lo[d]), min(wh, hi[d])
+                src.append(slice(a - wl, e - wl))
+                dst.append(slice(a - lo[d], e - lo[d]))
+            region[tuple(dst)] += tiles[c][tuple(src)]
+        for d in reversed(squeeze):
+            region = region.squeeze(d)
+        return region
+
+    def clear_cache(self):
+        self.tile_store.clear(self.tensor_id)

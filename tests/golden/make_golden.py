@@ -133,14 +133,18 @@ def gen_rng():
 
 def gen_geometry():
     from terrain_diffusion.training.evaluation import _linear_weight_window, _tile_starts
-    pano = extract_functions(os.path.join(REF, "annotated_infinite_panorama.py"), {"linear_kernel", "build_timestep_ranges"},
-                             {"np": np, "torch": torch})
+    pano = extract_functions(os.path.join(REF, "annotated_infinite_panorama.py"), {"linear_kernel", "build_timestep_ranges", "tiled_gaussian_noise"},
+                             {"np": np, "torch": torch, "LATENT_CHANNELS": 4, "LATENT_TILE": 64})
     wp = extract_functions(os.path.join(REF, "terrain_diffusion/inference/world_pipeline.py"), {"linear_weight_window", "normalize_tensor"},
                            {"np": np, "torch": torch})
     out = {}
     for s in (4, 16, 64, 512):
         out[f"lww_{s}"] = _linear_weight_window(s, torch.device("cpu"), torch.float32)[0, 0].numpy()
         assert torch.equal(wp["linear_weight_window"](s, torch.device("cpu"), torch.float32), torch.from_numpy(out[f"lww_{s}"]))
+    # SD-demo noise (annotated_infinite_panorama.py:57-73): windows straddling 256-column noise tiles, negative columns
+    out["pano_noise_s1234_x0"] = pano["tiled_gaussian_noise"](1234, 0, 64)
+    out["pano_noise_s1234_xm300"] = pano["tiled_gaussian_noise"](1234, -300, 64)
+    out["pano_noise_s7_x224_w96_c5"] = pano["tiled_gaussian_noise"](7, 224, 96, channels=5)
     out["pano_kernel_64"] = pano["linear_kernel"](64, 64).numpy()
     out["pano_kernel_8x512"] = pano["linear_kernel"](8, 512).numpy()
     cases = [(64, 64, 32), (288, 64, 32), (1056, 64, 32), (100, 64, 32), (65, 64, 32), (10, 64, 32), (96, 64, 32), (130, 64, 48), (512, 512, 384), (33, 16, 8)]

@@ -360,3 +360,62 @@ def test_sharded_sampling_simulated_ranks(td, orc):
         m.close()
     finally:
         eng.set_option("batch_invariant", 0)
+
+
+def test_infinite_latent_stage_vs_oracle(td, orc):
+    """Lazy 2-phase InfiniteDiffusion latent stage (InfiniteTensor graph on the engine, negative coordinates) vs an explicit CPU
+    restatement with the oracle U-Net: every window that touches the request, both phases, blend between phases."""
+    from terrain_diffusion_amd.pipeline import build_latent_stage
+    from oracle import tiling, rng
+    cfg = orc["unet"].tiny_config(64, 1)
+    sd_ = orc["unet"].synth_state_dict(cfg, seed=77)
+    m = td.EDMUnet2D(**cfg, dtype="fp32").load_state_dict(sd_)
+    om = orc["unet"].OracleUnet(cfg, sd_)
+    T, S, C, sdat, seed = 16, 8, 5, 0.5, 11
+    t1 = float(np.arctan(0.35 / 0.5))
+
+    def cond_fn(ctxs):
+        return torch.stack([torch.from_numpy(rng.standard_normal(5000 + 97 * c[1] + c[2], (58,))) for c in ctxs])
+
+    lat = build_latent_stage(m, seed=seed, cond_fn=cond_fn, intermediate_ts=(t1,), tile=T, batch_size=7)
+    y0, y1, x0, x1 = -4, 12, 6, 20
+    got = lat[:, y0:y1, x0:x1]
+    got = got[:-1] / got[-1:]
+    # explicit restatement
+    w = tiling.linear_weight_window(T)
+    t0 = float(torch.atan(torch.tensor(80.0) / sdat))
+
+    def touching(lo, hi):
+        return [k for k in range(-10, 10) if k * S < hi and k * S + T > lo]
+
+    memo = {}
+
+    def window(phase, i, j):
+        if (phase, i, j) in memo:
+            return memo[(phase, i, j)]
+        z = torch.from_numpy(rng.gaussian_noise_patch(seed + 5819 + phase, i * S, j * S, T, T, C, T, T))[None] * sdat
+        if phase == 0:
+            sample = torch.zeros(1, C, T, T)
+            t = torch.tensor(t0)
+        else:
+            acc = torch.zeros(C + 1, T, T)
+            for ii in touching(i * S, i * S + T):
+                for jj in touching(j * S, j * S + T):
+                    a, e, b, f_ = max(i * S, ii * S), min(i * S + T, ii * S + T), max(j * S, jj * S), min(j * S + T, jj * S + T)
+                    acc[:, a - i * S:e - i * S, b - j * S:f_ - j * S] += window(phase - 1, ii, jj)[:, a - ii * S:e - ii * S, b - jj * S:f_ - jj * S]
+            sample = (acc[:-1] / acc[-1:])[None] * sdat
+            t = torch.tensor(t1)
+        x_t = torch.cos(t) * sample + torch.sin(t) * z
+        pred = -om(x_t / sdat, t.view(1), [cond_fn([(0, i, j)])])
+        out = (torch.cos(t) * x_t - torch.sin(t) * sdat * pred)[0] / sdat
+        memo[(phase, i, j)] = torch.cat([out * w[None], w[None]])
+        return memo[(phase, i, j)]
+
+    acc = torch.zeros(C + 1, y1 - y0, x1 - x0)
+    for i in touching(y0, y1):
+        for j in touching(x0, x1):
+            a, e, b, f_ = max(y0, i * S), min(y1, i * S + T), max(x0, j * S), min(x1, j * S + T)
+            acc[:, a - y0:e - y0, b - x0:f_ - x0] += window(1, i, j)[:, a - i * S:e - i * S, b - j * S:f_ - j * S]
+    exp = acc[:-1] / acc[-1:]
+    assert rel_rms(got.numpy(), exp.numpy()) < 1e-5
+    m.close()
