@@ -154,21 +154,33 @@ def main():
         if not args.no_kernel_profile:
             # kernel-level: HIP events on the engine's own stream around every conv_igemm launch (eager, no graph)
             eng.set_option("profile", 1)
-            eng.profile_read(reset=True)
+            eng.profile_read(reset=True); eng.profile_read_glds(reset=True)
             one_step(10_000)
             sync()
+            g_ms, g_flop, g_n = eng.profile_read_glds(reset=True)
             conv_ms, conv_n, other_ms, other_n = eng.profile_read(reset=True)
             eng.set_option("profile", 0)
-            flop_per_launch = flop_per_step * CONV_SHARE / conv_n
-            avg_us = conv_ms / conv_n * 1e3
-            ach = flop_per_launch / (avg_us * 1e-6) / 1e12
-            roof.update({"achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches_per_step": conv_n,
-                         "avg_launch_us": round(avg_us, 3), "flop_per_launch": round(flop_per_launch),
-                         "conv_kernel_ms_per_step": round(conv_ms, 3), "other_unet_kernel_ms_per_step": round(other_ms, 3)})
-            if False:
-                gbs = E * WEIGHT_BYTES_BF16 / (conv_ms * 1e-3) / 1e9
-                roof["hbm_weight_stream"] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                             "note": "weights read once per forward at batch 1 (algorithmic minimum bytes)"}
+            roof.update({"all_conv_kernels_ms_per_step": round(conv_ms, 3), "all_conv_launches_per_step": conv_n,
+                         "other_unet_kernel_ms_per_step": round(other_ms, 3)})
+            if g_n > 0:   # dominant kernel family: the LDS-DMA implicit-GEMM conv (terrain_diffusion_amd/csrc/conv_glds.hip)
+                ach = g_flop / (g_ms * 1e-3) / 1e12
+                roof.update({"kernel": "td::conv_glds_kernel", "achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches_per_step": g_n,
+                             "avg_launch_us": round(g_ms / g_n * 1e3, 3), "flop_per_launch": round(g_flop / g_n),
+                             "kernel_ms_per_step": round(g_ms, 3), "share_of_unet_kernel_time": round(g_ms / (conv_ms + other_ms), 4)})
+            else:         # small-batch configurations never reach the LDS-DMA flavour
+                flop_per_launch = flop_per_step * CONV_SHARE / conv_n
+                ach = flop_per_launch / (conv_ms / conv_n * 1e-3) / 1e12
+                roof.update({"achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches_per_step": conv_n,
+                             "avg_launch_us": round(conv_ms / conv_n * 1e3, 3), "flop_per_launch": round(flop_per_launch)})
+            tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_and_mfma_util.json")
+            if os.path.exists(tpath) and args.workload == "tiles" and tiles_per_step == 64 and args.dtype == "bf16":
+                # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled per the
+                # MI355X guide's gfx950 correction, + WRITE_SIZE); not re-measured live (PMC collection needs rocprofv3)
+                tj = json.load(open(tpath))["kernels"]
+                ks_ = [v for k_, v in tj.items() if "conv_glds_kernel<16" in k_]
+                n_ = sum(v["dispatches"] for v in ks_)
+                roof["traffic"] = round(sum(v["dispatches"] * (v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]) for v in ks_) / n_)
+                roof["traffic_source"] = "profiles/r01_hbm_traffic_and_mfma_util.json"
         else:
             roof.update({"achieved": roof["end_to_end_achieved"], "frac": roof["end_to_end_frac"]})
         result["roofline"] = roof

@@ -65,6 +65,8 @@ int td_engine_set_option(td_engine* e, const char* key, int64_t value);
  * conv_igemm launch (and every other U-Net kernel); this reads/reset the accumulated kernel time and launch counts. */
 int td_engine_profile_read(td_engine* e, double* conv_ms, int64_t* conv_launches, double* other_ms, int64_t* other_launches, int reset);
 
+/* the LDS-DMA conv kernel family (td::conv_glds_kernel) alone: summed event time, algorithmic FLOP (2*pixels*Cout*K) and launches */
+int td_engine_profile_read_glds(td_engine* e, double* ms, double* flop, int64_t* launches, int reset);
 /* per-op breakdown of the same counters as text lines "label<TAB>ms<TAB>launches" (call before a resetting read) */
 int td_engine_profile_dump(td_engine* e, char* buf, int64_t capacity);
 

@@ -32,6 +32,7 @@ _SIGS = {
     "td_engine_stream": (_P, [_P]),
     "td_engine_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "td_engine_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
+    "td_engine_profile_read_glds": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     "td_engine_profile_dump": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "td_unet_create": (C.c_int, [_P, C.POINTER(UnetConfig), C.c_int, C.POINTER(_P)]),
     "td_unet_destroy": (None, [_P]),

@@ -70,6 +70,8 @@ struct td_engine {
     double prof_conv_ms = 0.0, prof_other_ms = 0.0;
     int64_t prof_conv_launches = 0, prof_other_launches = 0;
     std::map<std::string, std::pair<double, int64_t>> prof_ops;  // label -> (ms, launches)
+    double prof_glds_ms = 0.0, prof_glds_flop = 0.0;             // the LDS-DMA conv kernel family alone
+    int64_t prof_glds_launches = 0;
     int64_t option(const char* k, int64_t dflt) const { auto it = opt.find(k); return it == opt.end() ? dflt : it->second; }
 };
 
@@ -671,9 +673,10 @@ static int run_unet(td_unet* u, Plan& pl, int step) {
     std::vector<hipEvent_t> evs;
     std::vector<int> ev_kind;
     std::vector<std::string> ev_label;
+    std::vector<double> ev_flop;
     auto mark = [&]() { if (prof) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); evs.push_back(e); } };
     struct Fin {
-        td_unet* u; std::vector<hipEvent_t>& evs; std::vector<int>& kind; std::vector<std::string>& labels; hipStream_t st;
+        td_unet* u; std::vector<hipEvent_t>& evs; std::vector<int>& kind; std::vector<std::string>& labels; std::vector<double>& flop; hipStream_t st;
         ~Fin() {
             if (evs.empty()) return;
             (void)hipStreamSynchronize(st);
@@ -681,17 +684,18 @@ static int run_unet(td_unet* u, Plan& pl, int step) {
                 float ms = 0.f;
                 (void)hipEventElapsedTime(&ms, evs[i], evs[i + 1]);
                 auto& po = u->eng->prof_ops[labels[i / 2]]; po.first += ms; po.second++;
+                if (flop[i / 2] > 0) { u->eng->prof_glds_ms += ms; u->eng->prof_glds_flop += flop[i / 2]; u->eng->prof_glds_launches++; }
                 if (kind[i / 2] == 0) { u->eng->prof_conv_ms += ms; u->eng->prof_conv_launches++; } else { u->eng->prof_other_ms += ms; u->eng->prof_other_launches++; }
             }
             for (auto e : evs) (void)hipEventDestroy(e);
         }
-    } fin{u, evs, ev_kind, ev_label, st};
+    } fin{u, evs, ev_kind, ev_label, ev_flop, st};
     for (auto& op : pl.ops) {
         if (op.kind == Op::ATTN) {
             mark();
             if (u->bf16) hipLaunchKernelGGL(attn_kernel<__bf16>, dim3(pl.N, op.C / 64), dim3(256), 0, st, (const __bf16*)op.qkv, (__bf16*)op.att, op.tokens, op.C);
             else hipLaunchKernelGGL(attn_kernel<float>, dim3(pl.N, op.C / 64), dim3(256), 0, st, (const float*)op.qkv, (float*)op.att, op.tokens, op.C);
-            mark(); if (prof) { ev_kind.push_back(1); ev_label.push_back(op.label); }
+            mark(); if (prof) { ev_kind.push_back(1); ev_label.push_back(op.label); ev_flop.push_back(0.0); }
             HIP_TRY(hipGetLastError());
             continue;
         }
@@ -699,7 +703,9 @@ static int run_unet(td_unet* u, Plan& pl, int step) {
         if (op.cvec_off >= 0) p.cvec = cbase + op.cvec_off;
         mark();
         hipError_t e = op.flavor == 2 ? launch_conv_glds(p, op.narrow, op.bn, st) : launch_conv(p, u->bf16, op.narrow, op.bn, 0, st);
-        mark(); if (prof) { ev_kind.push_back(0); char tag[96]; snprintf(tag, sizeof tag, " [%dx%d k%d f%d bn%d wg%d ks%d]", p.H, p.W, p.kgroups, op.flavor, op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit); ev_label.push_back(op.label + tag); }
+        mark(); if (prof) { ev_kind.push_back(0); char tag[96]; snprintf(tag, sizeof tag, " [%dx%d k%d f%d bn%d wg%d ks%d]", p.H, p.W, p.kgroups, op.flavor, op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit); ev_label.push_back(op.label + tag);
+            double kk = 0; for (int s_ = 0; s_ < p.nseg; ++s_) kk += (double)p.seg[s_].C * p.seg[s_].taps;
+            ev_flop.push_back(op.flavor == 2 ? 2.0 * p.N * p.H * p.W * (double)p.Cout * kk : 0.0); }
         if (e != hipSuccess) return fail(TD_ERR_HIP, "conv launch " + op.label + ": " + hipGetErrorString(e));
     }
     return TD_OK;
@@ -745,6 +751,13 @@ int td_engine_profile_read(td_engine* e, double* conv_ms, int64_t* conv_launches
     if (other_ms) *other_ms = e->prof_other_ms;
     if (other_launches) *other_launches = e->prof_other_launches;
     if (reset) { e->prof_conv_ms = e->prof_other_ms = 0.0; e->prof_conv_launches = e->prof_other_launches = 0; e->prof_ops.clear(); }
+    return TD_OK;
+}
+int td_engine_profile_read_glds(td_engine* e, double* ms, double* flop, int64_t* launches, int reset) {
+    if (ms) *ms = e->prof_glds_ms;
+    if (flop) *flop = e->prof_glds_flop;
+    if (launches) *launches = e->prof_glds_launches;
+    if (reset) { e->prof_glds_ms = e->prof_glds_flop = 0.0; e->prof_glds_launches = 0; }
     return TD_OK;
 }
 int td_engine_profile_dump(td_engine* e, char* buf, int64_t capacity) {

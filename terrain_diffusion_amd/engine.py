@@ -29,6 +29,12 @@ class Engine:
         check(lib().td_engine_profile_read(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), int(reset)))
         return a.value, b.value, c.value, d.value
 
+    def profile_read_glds(self, reset=True):
+        """(ms, algorithmic_flop, launches) of the td::conv_glds_kernel launches recorded in profile mode."""
+        a, b, c = C.c_double(), C.c_double(), C.c_int64()
+        check(lib().td_engine_profile_read_glds(self._h, C.byref(a), C.byref(b), C.byref(c), int(reset)))
+        return a.value, b.value, c.value
+
     def profile_ops(self):
         """[(label, ms, launches)] per fused op, accumulated in profile mode."""
         buf = C.create_string_buffer(1 << 20)
