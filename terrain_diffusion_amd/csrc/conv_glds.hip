@@ -27,7 +27,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
 }
 
 template <int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_glds_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(const ConvParams p) {
     typedef __bf16 T;
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
     constexpr int TPIX = TH * TW, BM = NIMG * TPIX;
@@ -73,7 +73,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_glds_kernel(const
     TD_GLDS_B(0, 0);
     if (nk > 1) TD_GLDS_B(1, 1);
 
-    // ---- per-thread staging coordinates of the activation patch: packed (n, y, x, interior) or -1
+    // ---- activation-patch staging.  Per thread A_ITERS 16-byte pieces (patch pixel e>>3, slot e&7).  The packed coordinate is
+    // segment independent; the element offset of the piece inside a segment's source tensor (aoff) is recomputed once per SEGMENT,
+    // together with the segment descriptor (kept in registers: re-reading p.seg[] from kernarg memory inside the K loop costs a
+    // serialised s_load + s_waitcnt per field), so staging a K-group is just "base + chunk*64".
     int a_coord[A_ITERS];
 #pragma unroll
     for (int it = 0; it < A_ITERS; ++it) {
@@ -85,37 +88,47 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_glds_kernel(const
         a_coord[it] = ok ? ((n << 21) | (y << 11) | (x << 1) | (interior ? 1 : 0)) : -1;
     }
     u32x4 av[A_ITERS];
-#define TD_LOAD_A(SEG, CH)                                                                                            \
+    int aoff[A_ITERS];          // element offset of this thread's piece in the current segment's source, or -1 (zero fill)
+    const T* seg_src = nullptr;  // current segment descriptor, in registers
+    int seg_taps = 9, seg_xform = 0, seg_nchunks = 0;
+    float seg_scale = 1.f;
+#define TD_SEG_BEGIN(SEG)                                                                                             \
     {                                                                                                                 \
         const ConvSeg& sg_ = p.seg[SEG];                                                                              \
-        const T* src_ = (const T*)sg_.src + (CH) * CHUNK + (tid & 7) * PER16;                                         \
+        seg_src = (const T*)sg_.src; seg_taps = sg_.taps; seg_xform = sg_.xform; seg_scale = sg_.scale; seg_nchunks = sg_.C / CHUNK; \
+        const int Hs_ = sg_.Hs, Ws_ = sg_.Ws, rs_ = sg_.resample, cs_ = sg_.cstride;                                  \
         _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) {                                                   \
             const int c_ = a_coord[it_];                                                                              \
-            av[it_] = u32x4{0u, 0u, 0u, 0u};                                                                          \
-            if (c_ >= 0 && (sg_.taps == 9 || (c_ & 1))) {                                                             \
-                const int sp_ = src_pixel(c_ >> 21, (c_ >> 11) & 1023, (c_ >> 1) & 1023, sg_.Hs, sg_.Ws, sg_.resample); \
-                av[it_] = *(const u32x4*)(src_ + (size_t)sp_ * sg_.cstride);                                          \
-            }                                                                                                         \
+            aoff[it_] = -1;                                                                                           \
+            if (c_ >= 0 && (seg_taps == 9 || (c_ & 1)))                                                               \
+                aoff[it_] = src_pixel(c_ >> 21, (c_ >> 11) & 1023, (c_ >> 1) & 1023, Hs_, Ws_, rs_) * cs_ + (tid & 7) * PER16; \
         }                                                                                                             \
     }
-#define TD_STORE_A(SEG)                                                                                \
+#define TD_LOAD_A(CH)                                                                                  \
     {                                                                                                  \
-        const ConvSeg& sg_ = p.seg[SEG];                                                               \
+        const T* src_ = seg_src + (CH) * CHUNK;                                                        \
+        _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) {                                    \
+            av[it_] = u32x4{0u, 0u, 0u, 0u};                                                           \
+            if (aoff[it_] >= 0) av[it_] = *(const u32x4*)(src_ + aoff[it_]);                           \
+        }                                                                                              \
+    }
+#define TD_STORE_A()                                                                                   \
+    {                                                                                                  \
         _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) {                                    \
             const int e_ = tid + it_ * NTHR, pp_ = e_ >> 3, slot_ = e_ & 7;                            \
             if (pp_ < NPATCH) {                                                                        \
                 u32x4 v_ = av[it_];                                                                    \
-                if (sg_.xform != 0 && a_coord[it_] >= 0) {                                             \
-                    float s_ = sg_.scale;                                                              \
-                    if (sg_.xform == 2) s_ *= s_rn[pp_];                                               \
+                if (seg_xform != 0 && aoff[it_] >= 0) {                                                \
+                    float s_ = seg_scale;                                                              \
+                    if (seg_xform == 2) s_ *= s_rn[pp_];                                               \
                     v_ = xform_piece<T>(v_, s_);                                                       \
                 }                                                                                      \
                 *(u32x4*)(s_a + pp_ * 128 + ((slot_ ^ TD_SWZ(pp_)) << 4)) = v_;                        \
             }                                                                                          \
         }                                                                                              \
     }
-    int seg = 0, chunk = 0;
-    TD_LOAD_A(0, 0);
+    TD_SEG_BEGIN(0);
+    TD_LOAD_A(0);
 
     // ---- per-pixel 1/(eps + rms) of the pixel-normed source, for the patch pixels
     const float* rn_sumsq = nullptr; int rn_parts = 0, rn_Hs = 0, rn_Ws = 0, rn_res = 0; float rn_invc = 0.f;
@@ -157,25 +170,46 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_glds_kernel(const
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     __syncthreads();  // s_rn visible (prologue only: this one may drain the two weight tiles, they are needed next anyway)
-    TD_STORE_A(0);
+    TD_STORE_A();
 
     int k = 0, slot = 0;
-    const int ngroups = p.kgroups;
-    for (int g = 0; g < ngroups; ++g) {
-        const int taps = p.seg[seg].taps;
-        int nseg_ = seg, nchunk_ = chunk + 1;
-        if (nchunk_ == p.seg[seg].C / CHUNK) { nchunk_ = 0; ++nseg_; }
-        const bool has_next = g + 1 < ngroups;
+#ifdef TD_ABLATE_DSREAD
+#define TD_FRAG_READ(WF, XF, KS)                                                                             \
+    {                                                                                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) { WF[j_] = u32x4{(unsigned)woff[j_][KS], 1u, 2u, 3u}; asm volatile("" : "+v"(WF[j_])); } \
+        _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_) { XF[i_] = u32x4{(unsigned)xrow_[i_], 1u, 2u, 3u}; asm volatile("" : "+v"(XF[i_])); }   \
+    }
+#else
+#define TD_FRAG_READ(WF, XF, KS)                                                                             \
+    {                                                                                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) WF[j_] = *(const u32x4*)(sb_ + woff[j_][KS]);     \
+        _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_) XF[i_] = *(const u32x4*)(s_a + xrow_[i_] + ((((KS) * 2) ^ xswz_[i_]) << 4)); \
+    }
+#endif
+#ifdef TD_ABLATE_MFMA
+#define TD_FRAG_MFMA(WF, XF)                                                                                 \
+    {                                                                                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) asm volatile("" ::"v"(WF[j_]));                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_) asm volatile("" ::"v"(XF[i_]));                    \
+    }
+#else
+#define TD_FRAG_MFMA(WF, XF)                                                                                 \
+    {                                                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                                    \
+            _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                \
+                acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WF[j_]), __builtin_bit_cast(bf16x8, XF[i_]), acc[i_][j_], 0, 0, 0); \
+    }
+#endif
 #define TD_TAP(TAPIDX, DOFF)                                                                                 \
     {                                                                                                        \
         /* weight tile k must have landed: only the tile issued after it (k+1) may still be in flight */     \
         if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI) : "memory");                           \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
-        __builtin_amdgcn_s_barrier();                                                                        \
+        TD_ABL_BARRIER(__builtin_amdgcn_s_barrier());                                                        \
         asm volatile("" ::: "memory");                                                                       \
-        if ((TAPIDX) == 0 && has_next) TD_LOAD_A(nseg_, nchunk_);                                            \
-        if (k + 2 < nk) TD_GLDS_B(k + 2, slot == 0 ? 2 : slot - 1);                                          \
+        TD_ABL_BSTORE(if ((TAPIDX) == 0 && has_next) TD_LOAD_A(chunk + 1));                                  \
+        TD_ABL_BLOAD(if (k + 2 < nk) TD_GLDS_B(k + 2, slot == 0 ? 2 : slot - 1));                            \
         const unsigned char* sb_ = s_b + slot * B_BYTES;                                                     \
         int xrow_[MT], xswz_[MT];  /* recomputed per tap on purpose: hoisting 9 taps x 4 k-steps of addresses spills */ \
         _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_) {                                                  \
@@ -184,37 +218,64 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_glds_kernel(const
             pp_ += (DOFF);                                                                                   \
             xrow_[i_] = pp_ * 128; xswz_[i_] = TD_SWZ(pp_) ^ lh;                                             \
         }                                                                                                    \
-        _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                                \
-            u32x4 wf_[NT], xf_[MT];                                                                          \
-            _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) wf_[j_] = *(const u32x4*)(sb_ + woff[j_][ks_]); \
-            _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_) xf_[i_] = *(const u32x4*)(s_a + xrow_[i_] + (((ks_ * 2) ^ xswz_[i_]) << 4)); \
-            _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                                \
-                _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                            \
-                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf_[j_]), __builtin_bit_cast(bf16x8, xf_[i_]), acc[i_][j_], 0, 0, 0); \
-        }                                                                                                    \
+        u32x4 wfA_[NT], xfA_[MT], wfB_[NT], xfB_[MT];                                                        \
+        TD_FRAG_READ(wfA_, xfA_, 0);                                                                         \
+        TD_FRAG_READ(wfB_, xfB_, 1);                                                                         \
+        TD_FRAG_MFMA(wfA_, xfA_);                                                                            \
+        TD_FRAG_READ(wfA_, xfA_, 2);                                                                         \
+        TD_FRAG_MFMA(wfB_, xfB_);                                                                            \
+        TD_FRAG_READ(wfB_, xfB_, 3);                                                                         \
+        TD_FRAG_MFMA(wfA_, xfA_);                                                                            \
+        TD_FRAG_MFMA(wfB_, xfB_);                                                                            \
         slot = slot == 2 ? 0 : slot + 1;                                                                     \
         ++k;                                                                                                 \
     }
-        if (taps == 9) {
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) TD_TAP(tap, (tap / 3 - 1) * PW + (tap % 3 - 1));
-        } else {
-            TD_TAP(0, 0);
-        }
-        if (has_next) {
-            __builtin_amdgcn_s_barrier();  // every wave is done reading the current patch
+    for (int seg = 0; seg < p.nseg; ++seg) {
+        if (seg > 0) {  // first K-group of a later segment: its patch could not be prefetched (different source tensor / transform)
+            TD_SEG_BEGIN(seg);
+            TD_LOAD_A(0);
+            __builtin_amdgcn_s_barrier();  // every wave is done reading the previous patch
             asm volatile("" ::: "memory");
-            TD_STORE_A(nseg_);             // visible to the others after the next tap's lgkmcnt(0) + barrier
+            TD_STORE_A();                  // visible after the next tap's lgkmcnt(0) + barrier
         }
-        seg = nseg_; chunk = nchunk_;
+        for (int chunk = 0; chunk < seg_nchunks; ++chunk) {
+            const bool has_next = chunk + 1 < seg_nchunks;
+            if (seg_taps == 9) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) TD_TAP(tap, (tap / 3 - 1) * PW + (tap % 3 - 1));
+            } else {
+                TD_TAP(0, 0);
+            }
+            if (has_next) {
+                __builtin_amdgcn_s_barrier();  // every wave is done reading the current patch
+                asm volatile("" ::: "memory");
+                TD_ABL_BSTORE(TD_STORE_A());   // visible to the others after the next tap's lgkmcnt(0) + barrier
+            }
+        }
     }
 #undef TD_TAP
+#undef TD_FRAG_READ
+#undef TD_FRAG_MFMA
 #undef TD_LOAD_A
 #undef TD_STORE_A
+#undef TD_SEG_BEGIN
 #undef TD_GLDS_B
 
     // ---------------- epilogue: lane holds, per 32x32 tile, 4 groups of 4 consecutive couts of pixel column (lane & 31)
     const size_t M = (size_t)p.N * p.H * p.W;
+#ifdef TD_ABLATE_EPI
+    {
+        float t_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t_ += acc[i][j][r];
+        if (t_ == 12345.678f) ((float*)p.out)[tid] = t_;
+    }
+    if (p.N < 0)
+#endif
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int q = wm * WM + i * 32 + l31;
@@ -269,9 +330,16 @@ static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
     return hipGetLastError();
 }
 
-// wide: 16x16-pixel spatial tile; narrow (feature maps narrower than 16): 8x8 pixels x 4 images.
-// bn 128: waves 4(M) x 2(N), 64 px x 64 couts each; bn 96 (layer widths 192, 576): waves 8 x 1, 32 px x 96 couts each.
-hipError_t launch_conv_glds(const ConvParams& p, bool narrow, int bn, hipStream_t st) {
+// Tile configurations (variant):
+//   0 "big"   : 8 waves, 256-pixel tile (16x16, narrow maps 8x8 x 4 images), bn 128 -> waves 4x2 (64 px x 64 co), bn 96 -> 8x1 (32 px x 96 co);
+//               ~91 KB LDS -> one workgroup per CU
+//   1 "small" : 4 waves, 128-pixel tile (8x16, narrow maps 8x8 x 2 images), bn 128 -> waves 2x2 (64 px x 64 co), bn 96 -> 4x1 (32 px x 96 co);
+//               ~71 KB LDS -> two independent workgroups per CU whose prologues / epilogues / barrier stalls overlap
+hipError_t launch_conv_glds(const ConvParams& p, bool narrow, int bn, int variant, hipStream_t st) {
+    if (variant == 1) {
+        if (!narrow) return bn == 128 ? launch_glds_cfg<8, 16, 1, 128, 2, 2>(p, st) : launch_glds_cfg<8, 16, 1, 96, 4, 1>(p, st);
+        return bn == 128 ? launch_glds_cfg<8, 8, 2, 128, 2, 2>(p, st) : launch_glds_cfg<8, 8, 2, 96, 4, 1>(p, st);
+    }
     if (!narrow) return bn == 128 ? launch_glds_cfg<16, 16, 1, 128, 4, 2>(p, st) : launch_glds_cfg<16, 16, 1, 96, 8, 1>(p, st);
     return bn == 128 ? launch_glds_cfg<8, 8, 4, 128, 4, 2>(p, st) : launch_glds_cfg<8, 8, 4, 96, 8, 1>(p, st);
 }

@@ -151,6 +151,7 @@ struct Op {
     ConvParams p;
     bool narrow = false;
     int bn = 64;
+    int glds_variant = 0;      // 0: 8 waves x 256 pixels, 1: 4 waves x 128 pixels
     int flavor = 0;            // 0: per-tap register-staged kernel (conv_igemm.hip); 2: LDS-DMA throughput kernel (conv_glds.hip)
     int cvec_off = -1;         // EPI_EMB_SILU: offset of this block's c vector
     int out_C = 0, out_H = 0, out_W = 0;  // output tensor geometry (debug read-back)
@@ -702,7 +703,7 @@ static int run_unet(td_unet* u, Plan& pl, int step) {
         ConvParams p = op.p;
         if (op.cvec_off >= 0) p.cvec = cbase + op.cvec_off;
         mark();
-        hipError_t e = op.flavor == 2 ? launch_conv_glds(p, op.narrow, op.bn, st) : launch_conv(p, u->bf16, op.narrow, op.bn, 0, st);
+        hipError_t e = op.flavor == 2 ? launch_conv_glds(p, op.narrow, op.bn, op.glds_variant, st) : launch_conv(p, u->bf16, op.narrow, op.bn, 0, st);
         mark(); if (prof) { ev_kind.push_back(0); char tag[96]; snprintf(tag, sizeof tag, " [%dx%d k%d f%d bn%d wg%d ks%d]", p.H, p.W, p.kgroups, op.flavor, op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit); ev_label.push_back(op.label + tag);
             double kk = 0; for (int s_ = 0; s_ < p.nseg; ++s_) kk += (double)p.seg[s_].C * p.seg[s_].taps;
             ev_flop.push_back(op.flavor == 2 ? 2.0 * p.N * p.H * p.W * (double)p.Cout * kk : 0.0); }

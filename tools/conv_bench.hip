@@ -33,11 +33,11 @@ int main(int argc, char** argv) {
     p.epi = EPI_PLAIN; p.out = out; p.out_cstride = Cout;
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) CK((flavor == 2 ? launch_conv_glds(p, narrow, bn, st) : launch_conv(p, true, narrow, bn, flavor, st)));
+    for (int i = 0; i < 3; ++i) CK((flavor >= 2 ? launch_conv_glds(p, narrow, bn, flavor - 2, st) : launch_conv(p, true, narrow, bn, flavor, st)));
     CK(hipStreamSynchronize(st));
     const int reps = 20;
     CK(hipEventRecord(e0, st));
-    for (int i = 0; i < reps; ++i) CK((flavor == 2 ? launch_conv_glds(p, narrow, bn, st) : launch_conv(p, true, narrow, bn, flavor, st)));
+    for (int i = 0; i < reps; ++i) CK((flavor >= 2 ? launch_conv_glds(p, narrow, bn, flavor - 2, st) : launch_conv(p, true, narrow, bn, flavor, st)));
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     double flop = 2.0 * M * Cout * Cin * taps;
