@@ -30,8 +30,7 @@ enum { TD_OK = 0, TD_ERR_ARG = -1, TD_ERR_HIP = -2, TD_ERR_STATE = -3, TD_ERR_UN
 enum { TD_DTYPE_F32 = 0, TD_DTYPE_BF16 = 1 };
 
 /* EDMUnet2D constructor arguments that shape the inference graph
- * (terrain_diffusion/models/edm_unet.py:17-37).  `cond_dim` describes the single ["tensor", cond_dim, w]
- * conditional input of the base model (configs/diffusion_base/30m/diffusion_192-3.cfg:66); 0 = none. */
+ * (terrain_diffusion/models/edm_unet.py:17-37). */
 typedef struct td_unet_config {
     int32_t image_size;            /* only used for block names / attention resolution test */
     int32_t in_channels, out_channels;
@@ -45,8 +44,13 @@ typedef struct td_unet_config {
     float concat_balance;
     int32_t noise_emb_dims;        /* 0 -> model_channels */
     int32_t emb_channels;          /* 0 -> model_channels * max(mults) */
-    int32_t cond_dim;
-    float cond_weight;
+    /* conditional_inputs of the constructor, in order (edm_unet.py:95-99): type 0 = ["tensor", dim, w] (base model: one 58-vector),
+     * type 1 = ["float", fourier_dims, w] (coarse model: five scalars through MPFourier, mp_layers.py:109-131); the decoder has none.
+     * A sample's conditioning row is the concatenation of its inputs in this order (tensor: dim floats, float: 1 float). */
+    int32_t n_cond;
+    int32_t cond_type[8];
+    int32_t cond_dims[8];
+    float cond_weights[8];
 } td_unet_config;
 
 const char* td_last_error(void);
@@ -86,8 +90,9 @@ int td_unet_set_param(td_unet* u, const char* name, const float* host_data, int6
 int td_unet_set_prefolded(td_unet* u, int prefolded);
 int td_unet_finalize(td_unet* u);
 
-/* model(x, noise_labels=t, conditional_inputs=[cond]) -> F      (edm_unet.py:161-184)
- * x: [n][in_channels][H][W], t: host [n], cond: [n][cond_dim], out: [n][out_channels][H][W] */
+/* model(x, noise_labels=t, conditional_inputs=[...]) -> F      (edm_unet.py:161-184)
+ * x: [n][in_channels][H][W], t: host [n], cond: [n][cond_row_len] (see td_unet_config), out: [n][out_channels][H][W] */
+int td_unet_cond_row_len(td_unet* u);
 int td_unet_forward(td_unet* u, int n, int H, int W, const float* x, const float* t_host, const float* cond, float* out);
 
 /* Test/debug facility: after a td_unet_forward(n,H,W), copies the OUTPUT of the fused conv op `label` (e.g. "enc.512x512_block0.conv_res1",
@@ -117,6 +122,14 @@ int td_sample_edm(td_unet* u, int n, int H, int W, int n_steps, const float* sig
  * sample may be NULL (zeros, first phase). */
 int td_sample_consistency(td_unet* u, int n, int H, int W, float t, float sigma_data, const float* sample, const float* z,
                           const float* cond, float* out);
+/* Same two samplers for models whose input = [sample channels | conditioning-image channels] (in_channels = out_channels + cimg):
+ * the coarse stage (world_pipeline.py:928-949: 6 sample + 5 noised-map channels) and the decoder (world_pipeline.py:1221-1239:
+ * 1 sample + 4 upsampled-latent channels).  cond_img: [n][cimg_channels][H][W], constant over the steps; x / sample / z / out carry
+ * out_channels channels. */
+int td_sample_edm_img(td_unet* u, int n, int H, int W, int n_steps, const float* sigmas_host, float sigma_data, const float* cond,
+                      const float* cond_img, int cimg_channels, float* x);
+int td_sample_consistency_img(td_unet* u, int n, int H, int W, float t, float sigma_data, const float* sample, const float* z,
+                              const float* cond, const float* cond_img, int cimg_channels, float* out);
 
 /* ---- overlap blend (sample_diffusion_base.py:164-168; annotated_infinite_panorama.py:145-150) ----------------
  * canvas: (C+1, Hc, Wc) fp32, weighted sums + weight channel.  Adds window i (tiles[i] = [C][size][size]) at

@@ -14,6 +14,13 @@ import torch.nn.functional as F
 
 from . import rng
 
+COARSE_CONFIG = dict(image_size=16, in_channels=11, out_channels=6, model_channels=128, model_channel_mults=[1], layers_per_block=2,
+                     attn_resolutions=[], midblock_attention=False, concat_balance=0.5, conditional_inputs=[["float", 64, 0.2]] * 5,
+                     fourier_scale="pos")   # configs/diffusion_coarse/diffusion_coarse_30m.cfg:47-62
+DECODER_CONFIG = dict(image_size=512, in_channels=5, out_channels=1, model_channels=64, model_channel_mults=[1, 2, 3, 4], layers_per_block=3,
+                      attn_resolutions=[], midblock_attention=False, concat_balance=0.5, conditional_inputs=[],
+                      fourier_scale="pos")  # configs/diffusion_decoder/diffusion_decoder_64-3.cfg:51-65
+
 BASE_CONFIG = dict(image_size=512, in_channels=5, out_channels=5, model_channels=192,
                    model_channel_mults=[1, 2, 3, 4], layers_per_block=3, attn_resolutions=[8, 16],
                    midblock_attention=True, concat_balance=0.5, conditional_inputs=[["tensor", 58, 1.0]],
@@ -193,12 +200,16 @@ class OracleUnet:
         self.w = {}
         self.w["noise_linear"] = f("noise_linear.weight")
         self.freqs = sd["noise_fourier.freqs"].to(torch.float32)
-        self.cond_w = []
+        self.cond_w = []       # (type, folded weight, freqs, phases)
         self.cond_weights = [1.0]
         for i, (typ, x, wt) in enumerate(cfg.get("conditional_inputs", [])):
-            if typ != "tensor":
+            if typ == "tensor":
+                self.cond_w.append(("tensor", f(f"conditional_layers.{i}.weight"), None, None))
+            elif typ == "float":   # nn.Sequential(MPFourier(x), MPConv(x, emb)) — edm_unet.py:96-97, mp_layers.py:109-131
+                self.cond_w.append(("float", f(f"conditional_layers.{i}.1.weight"), sd[f"conditional_layers.{i}.0.freqs"].to(torch.float32),
+                                    sd[f"conditional_layers.{i}.0.phases"].to(torch.float32)))
+            else:
                 raise NotImplementedError(typ)
-            self.cond_w.append(f(f"conditional_layers.{i}.weight"))
             self.cond_weights.append(float(wt))
         for b in self.plan["enc"] + self.plan["dec"]:
             n = b["name"]
@@ -218,8 +229,12 @@ class OracleUnet:
     # edm_unet.py:145-159
     def embeddings(self, noise_labels, conditional_inputs):
         embeds = [F.linear(pos_embedding(noise_labels, self.freqs).to(self.dtype), self.w["noise_linear"])]
-        for w, c in zip(self.cond_w, conditional_inputs):
-            embeds.append(mp_silu(F.linear(c.to(self.dtype), w)))
+        for (typ, w, fr, ph), c in zip(self.cond_w, conditional_inputs):
+            if typ == "tensor":
+                embeds.append(mp_silu(F.linear(c.to(self.dtype), w)))          # MPConv inputs get mp_silu (edm_unet.py:152-153)
+            else:
+                y = c.to(torch.float32).outer(fr) + ph                          # MPFourier (mp_layers.py:115-131), no mp_silu
+                embeds.append(F.linear((y.cos() * math.sqrt(2)).to(self.dtype), w))
         ws = torch.tensor(self.cond_weights, dtype=self.dtype)
         emb = sum(e * wi for e, wi in zip(embeds, ws)) / torch.linalg.vector_norm(ws)
         return mp_silu(emb)

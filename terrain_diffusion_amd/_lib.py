@@ -14,8 +14,8 @@ class UnetConfig(C.Structure):
                 ("model_channels", C.c_int32), ("n_levels", C.c_int32), ("channel_mults", C.c_int32 * 8),
                 ("layers_per_block", C.c_int32 * 8), ("n_attn_resolutions", C.c_int32),
                 ("attn_resolutions", C.c_int32 * 8), ("midblock_attention", C.c_int32), ("concat_balance", C.c_float),
-                ("noise_emb_dims", C.c_int32), ("emb_channels", C.c_int32), ("cond_dim", C.c_int32),
-                ("cond_weight", C.c_float)]
+                ("noise_emb_dims", C.c_int32), ("emb_channels", C.c_int32), ("n_cond", C.c_int32),
+                ("cond_type", C.c_int32 * 8), ("cond_dims", C.c_int32 * 8), ("cond_weights", C.c_float * 8)]
 
 
 class TdError(RuntimeError):
@@ -41,6 +41,7 @@ _SIGS = {
     "td_unet_set_param": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
     "td_unet_set_prefolded": (C.c_int, [_P, C.c_int]),
     "td_unet_finalize": (C.c_int, [_P]),
+    "td_unet_cond_row_len": (C.c_int, [_P]),
     "td_unet_forward": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "td_unet_read_activation": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int32 * 4)]),
     "td_tile_seed": (C.c_uint64, [C.c_uint64, C.c_int64, C.c_int64]),
@@ -49,6 +50,8 @@ _SIGS = {
     "td_schedule_karras": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_float, _P, _P]),
     "td_sample_edm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, _P]),
     "td_sample_consistency": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P]),
+    "td_sample_edm_img": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, _P, C.c_int, _P]),
+    "td_sample_consistency_img": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, C.c_int, _P]),
     "td_blend_windows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int]),
     "td_blend_normalize": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "td_linear_weight_window": (C.c_int, [_P, C.c_int, _P]),

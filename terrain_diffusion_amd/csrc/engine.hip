@@ -192,7 +192,9 @@ struct td_unet {
     bool finalized = false;
     bool prefolded = false;    // parameters already carry the MP normalisation and gains (host folded them)
     // embedding weights on device (fp32)
-    Buf d_freqs, d_wnoise, d_wcond, d_wemb, d_blk_woff, d_blk_coff, d_blk_cout;
+    Buf d_freqs, d_wnoise, d_wcond, d_fourier, d_wemb, d_blk_woff, d_blk_coff, d_blk_cout;
+    EmbDesc embd;              // conditional-input layout of the embedding kernel
+    int cond_row_len = 0;
     int n_blocks = 0;
     std::map<std::string, std::unique_ptr<Plan>> plans;
     size_t esize() const { return bf16 ? 2 : 4; }
@@ -256,7 +258,16 @@ static int build_blocks(td_unet* u) {
     add_param(u, "out_gain", {});
     add_param(u, "noise_fourier.freqs", {u->noise_dims / 2});
     add_param(u, "noise_linear.weight", {u->emb_ch, u->noise_dims});
-    if (c.cond_dim > 0) add_param(u, "conditional_layers.0.weight", {u->emb_ch, c.cond_dim});
+    if (c.n_cond < 0 || c.n_cond > 8) return fail(TD_ERR_ARG, "n_cond out of range");
+    for (int i = 0; i < c.n_cond; ++i) {
+        const std::string pre = "conditional_layers." + std::to_string(i);
+        if (c.cond_type[i] == 0) add_param(u, pre + ".weight", {u->emb_ch, c.cond_dims[i]});
+        else if (c.cond_type[i] == 1) {
+            add_param(u, pre + ".0.freqs", {c.cond_dims[i]});
+            add_param(u, pre + ".0.phases", {c.cond_dims[i]});
+            add_param(u, pre + ".1.weight", {u->emb_ch, c.cond_dims[i]});
+        } else return fail(TD_ERR_UNSUPPORTED, "conditional input type (embedding tables are not on the accelerated path)");
+    }
     int coff = 0;
     auto add_block = [&](Block& b) {
         if (b.is_conv) { add_param(u, b.name + ".weight", {b.cout, b.cin, 3, 3}); return; }
@@ -354,7 +365,33 @@ static int finalize(td_unet* u) {
         };
         if ((rc = up(u->d_freqs, P(u, "noise_fourier.freqs").data))) return rc;
         if ((rc = up(u->d_wnoise, *folded("noise_linear.weight", 1.f)))) return rc;
-        if (u->cfg.cond_dim > 0 && (rc = up(u->d_wcond, *folded("conditional_layers.0.weight", 1.f)))) return rc;
+        {
+            std::vector<float> wc, fr;
+            EmbDesc& d = u->embd;
+            memset(&d, 0, sizeof d);
+            d.n = u->cfg.n_cond;
+            double wsq = 1.0;
+            for (int i = 0; i < d.n; ++i) {
+                const std::string pre = "conditional_layers." + std::to_string(i);
+                d.type[i] = u->cfg.cond_type[i]; d.dims[i] = u->cfg.cond_dims[i]; d.weight[i] = u->cfg.cond_weights[i];
+                d.xoff[i] = d.row_len; d.row_len += d.type[i] == 0 ? d.dims[i] : 1;
+                d.foff[i] = d.feat_total; d.feat_total += d.dims[i];
+                d.woff[i] = (int)wc.size();
+                const std::vector<float>* w = folded(pre + (d.type[i] == 0 ? ".weight" : ".1.weight"), 1.f);
+                wc.insert(wc.end(), w->begin(), w->end());
+                if (d.type[i] == 1) {
+                    d.froff[i] = (int)fr.size();
+                    const auto& f = P(u, pre + ".0.freqs").data; const auto& ph = P(u, pre + ".0.phases").data;
+                    fr.insert(fr.end(), f.begin(), f.end()); fr.insert(fr.end(), ph.begin(), ph.end());
+                }
+                wsq += (double)d.weight[i] * d.weight[i];
+            }
+            d.inv_norm = (float)(1.0 / sqrt(wsq));
+            u->cond_row_len = d.row_len;
+            if (wc.empty()) wc.push_back(0.f);
+            if (fr.empty()) fr.push_back(0.f);
+            if ((rc = up(u->d_wcond, wc)) || (rc = up(u->d_fourier, fr))) return rc;
+        }
         std::vector<float> wall;
         std::vector<int> woff, coff, cout;
         auto add = [&](const Block& b) {
@@ -628,10 +665,10 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
         pl.partial = (float*)pp;
         for (auto& op : pl.ops) if (op.kind == Op::CONV) op.p.partial = pl.partial;
     }
-    const size_t xbytes = (size_t)N * u->cfg.in_channels * H * W * 4;
+    const size_t xbytes = (size_t)N * std::max(u->cfg.in_channels, u->cfg.out_channels) * H * W * 4;
     pl.x.reset(new DevBuf()); pl.m1.reset(new DevBuf()); pl.xt.reset(new DevBuf()); pl.cond.reset(new DevBuf());
     HIP_TRY(pl.x->alloc(xbytes)); HIP_TRY(pl.m1->alloc(xbytes)); HIP_TRY(pl.xt->alloc(xbytes));
-    HIP_TRY(pl.cond->alloc((size_t)N * std::max(1, u->cfg.cond_dim) * 4));
+    HIP_TRY(pl.cond->alloc((size_t)N * std::max(1, u->cond_row_len) * 4));
     HIP_TRY(hipDeviceSynchronize());  // buffer memsets ran on the null stream; the engine stream is non-blocking
     *out = plp.get();
     u->plans[key] = std::move(plp);
@@ -651,9 +688,9 @@ static int compute_cvecs(td_unet* u, Plan& pl, const std::vector<float>& t_steps
     }
     HIP_TRY(hipMemcpyAsync(pl.tsteps->p, t_steps.data(), t_steps.size() * 4, hipMemcpyHostToDevice, st));
     const int half = u->noise_dims / 2;
-    hipLaunchKernelGGL(emb_kernel, dim3(rows), dim3(256), (size_t)(2 * half + u->cfg.cond_dim) * 4, st, (const float*)pl.tsteps->p, d_cond, pl.N,
-                       (const float*)u->d_freqs->p, half, (const float*)u->d_wnoise->p, u->cfg.cond_dim > 0 ? (const float*)u->d_wcond->p : nullptr,
-                       u->cfg.cond_dim, u->cfg.cond_weight, u->emb_ch, (float*)pl.emb->p);
+    hipLaunchKernelGGL(emb_kernel, dim3(rows), dim3(256), (size_t)(2 * half + u->embd.feat_total) * 4, st, (const float*)pl.tsteps->p, d_cond, pl.N,
+                       (const float*)u->d_freqs->p, half, (const float*)u->d_wnoise->p, (const float*)u->d_wcond->p, (const float*)u->d_fourier->p,
+                       u->embd, u->emb_ch, (float*)pl.emb->p);
     int max_cout = 64;
     for (auto& b : u->enc) max_cout = std::max(max_cout, b.cout);
     for (auto& b : u->dec) max_cout = std::max(max_cout, b.cout);
@@ -816,6 +853,8 @@ int td_unet_finalize(td_unet* u) {
     return finalize(u);
 }
 
+int td_unet_cond_row_len(td_unet* u) { return u->cond_row_len; }
+
 int td_unet_forward(td_unet* u, int n, int H, int W, const float* x, const float* t_host, const float* cond, float* out) {
     if (!u->finalized) return fail(TD_ERR_STATE, "finalize first");
     Plan* pl;
@@ -827,7 +866,7 @@ int td_unet_forward(td_unet* u, int n, int H, int W, const float* x, const float
     std::vector<Buf> hold;
     const void *dx, *dcond = nullptr;
     if ((rc = to_device(e, x, (size_t)n * C * HW * 4, hold, &dx))) return rc;
-    if (u->cfg.cond_dim > 0 && (rc = to_device(e, cond, (size_t)n * u->cfg.cond_dim * 4, hold, &dcond))) return rc;
+    if (u->cond_row_len > 0 && (rc = to_device(e, cond, (size_t)n * u->cond_row_len * 4, hold, &dcond))) return rc;
     OutStage os;
     if ((rc = out_device(e, out, (size_t)n * Co * HW * 4, hold, &os))) return rc;
     // per-sample t: treat every sample as its own "step" row set (rows = n steps x n tiles would be wasteful): run per distinct t
@@ -847,8 +886,8 @@ int td_unet_forward(td_unet* u, int n, int H, int W, const float* x, const float
                                    hipMemcpyDeviceToDevice, st));
         }
     }
-    if (u->bf16) hipLaunchKernelGGL(prep_input_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)dx, (__bf16*)pl->xin, n, C, HW, u->chunk, 1.f);
-    else hipLaunchKernelGGL(prep_input_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)dx, (float*)pl->xin, n, C, HW, u->chunk, 1.f);
+    if (u->bf16) hipLaunchKernelGGL(prep_input_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)dx, (__bf16*)pl->xin, n, C, HW, u->chunk, 1.f, C);
+    else hipLaunchKernelGGL(prep_input_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)dx, (float*)pl->xin, n, C, HW, u->chunk, 1.f, C);
     if ((rc = run_unet(u, *pl, 0))) return rc;
     hipLaunchKernelGGL(unpack_output_kernel, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->F, (float*)os.dev, n, Co, HW, 8, 1.f);
     HIP_TRY(hipGetLastError());
@@ -949,7 +988,22 @@ static void dpm_coefs(const float* sig, int n_steps, float sigma_data, std::vect
     }
 }
 
-int td_sample_edm(td_unet* u, int n, int H, int W, int n_steps, const float* sigmas_host, float sigma_data, const float* cond, float* x) {
+// writes the conditioning-image channels [Cs, Cs+cimg) of the NHWC model input (constant over the solver steps)
+static int stage_cond_img(td_unet* u, Plan& pl, int n, int HW, const float* cond_img, int cimg, int Cs, std::vector<Buf>& hold) {
+    if (cimg == 0) return TD_OK;
+    if (!cond_img) return fail(TD_ERR_ARG, "cond_img is null");
+    const void* dimg;
+    int rc = to_device(u->eng, cond_img, (size_t)n * cimg * HW * 4, hold, &dimg);
+    if (rc) return rc;
+    hipStream_t st = u->eng->stream;
+    if (u->bf16) hipLaunchKernelGGL(write_cond_img_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)dimg, (__bf16*)pl.xin, n, cimg, HW, u->chunk, Cs);
+    else hipLaunchKernelGGL(write_cond_img_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)dimg, (float*)pl.xin, n, cimg, HW, u->chunk, Cs);
+    HIP_TRY(hipGetLastError());
+    return TD_OK;
+}
+
+int td_sample_edm_img(td_unet* u, int n, int H, int W, int n_steps, const float* sigmas_host, float sigma_data, const float* cond,
+                      const float* cond_img, int cimg, float* x) {
     if (!u->finalized) return fail(TD_ERR_STATE, "finalize first");
     if (n_steps < 1) return fail(TD_ERR_ARG, "n_steps");
     Plan* pl;
@@ -957,15 +1011,17 @@ int td_sample_edm(td_unet* u, int n, int H, int W, int n_steps, const float* sig
     if (rc) return rc;
     td_engine* e = u->eng;
     hipStream_t st = e->stream;
-    const int C = u->cfg.in_channels, HW = H * W;
-    if (u->cfg.out_channels != C) return fail(TD_ERR_UNSUPPORTED, "EDM sampler needs in_channels == out_channels");
+    const int Cin = u->cfg.in_channels, C = u->cfg.out_channels, HW = H * W;
+    if (C + cimg != Cin) return fail(TD_ERR_ARG, "in_channels must equal out_channels + conditioning-image channels");
     const size_t xbytes = (size_t)n * C * HW * 4;
     const bool x_dev = is_device_ptr(x);
+    std::vector<Buf> hold;
     HIP_TRY(hipMemcpyAsync(pl->x->p, x, xbytes, x_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-    if (u->cfg.cond_dim > 0) {
-        const size_t cb = (size_t)n * u->cfg.cond_dim * 4;
+    if (u->cond_row_len > 0) {
+        const size_t cb = (size_t)n * u->cond_row_len * 4;
         HIP_TRY(hipMemcpyAsync(pl->cond->p, cond, cb, is_device_ptr(cond) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     }
+    if ((rc = stage_cond_img(u, *pl, n, HW, cond_img, cimg, C, hold))) return rc;
     std::vector<float> ts(n_steps);
     for (int i = 0; i < n_steps; ++i) ts[i] = atanf(sigmas_host[i] / sigma_data);  // trigflow_precondition_noise (dpmsolver.py:240-242)
     if ((rc = compute_cvecs(u, *pl, ts, (const float*)pl->cond->p))) return rc;
@@ -974,8 +1030,8 @@ int td_sample_edm(td_unet* u, int n, int H, int W, int n_steps, const float* sig
     const float c_in0 = 1.f / sqrtf(sigmas_host[0] * sigmas_host[0] + sigma_data * sigma_data);
 
     auto enqueue = [&]() -> int {
-        if (u->bf16) hipLaunchKernelGGL(prep_input_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (__bf16*)pl->xin, n, C, HW, u->chunk, c_in0);
-        else hipLaunchKernelGGL(prep_input_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (float*)pl->xin, n, C, HW, u->chunk, c_in0);
+        if (u->bf16) hipLaunchKernelGGL(prep_input_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (__bf16*)pl->xin, n, C, HW, u->chunk, c_in0, Cin);
+        else hipLaunchKernelGGL(prep_input_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (float*)pl->xin, n, C, HW, u->chunk, c_in0, Cin);
         for (int i = 0; i < n_steps; ++i) {
             int r = run_unet(u, *pl, i);
             if (r) return r;
@@ -1009,34 +1065,45 @@ int td_sample_edm(td_unet* u, int n, int H, int W, int n_steps, const float* sig
     return TD_OK;
 }
 
-int td_sample_consistency(td_unet* u, int n, int H, int W, float t, float sigma_data, const float* sample, const float* z, const float* cond, float* out) {
+int td_sample_edm(td_unet* u, int n, int H, int W, int n_steps, const float* sigmas_host, float sigma_data, const float* cond, float* x) {
+    return td_sample_edm_img(u, n, H, W, n_steps, sigmas_host, sigma_data, cond, nullptr, 0, x);
+}
+
+int td_sample_consistency_img(td_unet* u, int n, int H, int W, float t, float sigma_data, const float* sample, const float* z, const float* cond,
+                              const float* cond_img, int cimg, float* out) {
     if (!u->finalized) return fail(TD_ERR_STATE, "finalize first");
     Plan* pl;
     int rc = build_plan(u, n, H, W, &pl);
     if (rc) return rc;
     td_engine* e = u->eng;
     hipStream_t st = e->stream;
-    const int C = u->cfg.in_channels, HW = H * W;
+    const int Cin = u->cfg.in_channels, C = u->cfg.out_channels, HW = H * W;
+    if (C + cimg != Cin) return fail(TD_ERR_ARG, "in_channels must equal out_channels + conditioning-image channels");
     const size_t xbytes = (size_t)n * C * HW * 4;
     std::vector<Buf> hold;
     const void* dz;
     if ((rc = to_device(e, z, xbytes, hold, &dz))) return rc;
     if (sample) HIP_TRY(hipMemcpyAsync(pl->x->p, sample, xbytes, is_device_ptr(sample) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     else HIP_TRY(hipMemsetAsync(pl->x->p, 0, xbytes, st));
-    if (u->cfg.cond_dim > 0)
-        HIP_TRY(hipMemcpyAsync(pl->cond->p, cond, (size_t)n * u->cfg.cond_dim * 4, is_device_ptr(cond) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    if (u->cond_row_len > 0)
+        HIP_TRY(hipMemcpyAsync(pl->cond->p, cond, (size_t)n * u->cond_row_len * 4, is_device_ptr(cond) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    if ((rc = stage_cond_img(u, *pl, n, HW, cond_img, cimg, C, hold))) return rc;
     if ((rc = compute_cvecs(u, *pl, std::vector<float>(1, t), (const float*)pl->cond->p))) return rc;
     OutStage os;
     if ((rc = out_device(e, out, xbytes, hold, &os))) return rc;
     const float ct = cosf(t), sn = sinf(t);
-    if (u->bf16) hipLaunchKernelGGL(consistency_pre_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (const float*)dz, (float*)pl->xt->p, (__bf16*)pl->xin, n, C, HW, u->chunk, ct, sn, sigma_data);
-    else hipLaunchKernelGGL(consistency_pre_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (const float*)dz, (float*)pl->xt->p, (float*)pl->xin, n, C, HW, u->chunk, ct, sn, sigma_data);
+    if (u->bf16) hipLaunchKernelGGL(consistency_pre_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (const float*)dz, (float*)pl->xt->p, (__bf16*)pl->xin, n, C, HW, u->chunk, ct, sn, sigma_data, Cin);
+    else hipLaunchKernelGGL(consistency_pre_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (const float*)dz, (float*)pl->xt->p, (float*)pl->xin, n, C, HW, u->chunk, ct, sn, sigma_data, Cin);
     if ((rc = run_unet(u, *pl, 0))) return rc;
     hipLaunchKernelGGL(consistency_post_kernel, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->xt->p, (const float*)pl->F, (float*)os.dev, n, C, HW, 8, ct, sn, sigma_data);
     HIP_TRY(hipGetLastError());
     if ((rc = out_finish(e, os))) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     return TD_OK;
+}
+
+int td_sample_consistency(td_unet* u, int n, int H, int W, float t, float sigma_data, const float* sample, const float* z, const float* cond, float* out) {
+    return td_sample_consistency_img(u, n, H, W, t, sigma_data, sample, z, cond, nullptr, 0, out);
 }
 
 // ---- noise

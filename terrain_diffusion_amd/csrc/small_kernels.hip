@@ -17,34 +17,53 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------ embeddings
-// edm_unet.py:145-159 + mp_layers.py:96-107: emb[row] = mp_silu( (noise_linear(posemb(t)) + w_c*mp_silu(cond_linear(cond))) / ||w|| )
+// edm_unet.py:145-159 + mp_layers.py:96-131:
+//   emb[row] = mp_silu( (noise_linear(posemb(t)) + sum_i w_i * e_i) / ||(1, w)|| ),
+//   e_i = mp_silu(linear_i(cond_i)) for a "tensor" input, linear_i(cos(x*freqs_i + phases_i)*sqrt2) for a "float" input (no mp_silu).
 // rows = (step, tile); t depends on step only, cond on tile only.  One workgroup per row, one wave per output.
+struct EmbDesc {
+    int n, row_len, feat_total;
+    int type[8], dims[8], xoff[8], foff[8], woff[8], froff[8];
+    float weight[8];
+    float inv_norm;
+};
 __global__ __launch_bounds__(256) void emb_kernel(const float* __restrict__ t_steps, const float* __restrict__ cond, int n_tiles,
                                                   const float* __restrict__ freqs, int half, const float* __restrict__ w_noise,
-                                                  const float* __restrict__ w_cond, int cond_dim, float cond_weight, int emb_ch,
+                                                  const float* __restrict__ w_cond, const float* __restrict__ fourier, EmbDesc d, int emb_ch,
                                                   float* __restrict__ emb) {
-    extern __shared__ float sh[];  // posemb[2*half] + cond[cond_dim]
+    extern __shared__ float sh[];  // posemb[2*half] + cond features[feat_total]
     const int row = blockIdx.x, step = row / n_tiles, tile = row % n_tiles;
     const float t = t_steps[step];
+    const int nd = 2 * half;
     for (int i = threadIdx.x; i < half; i += blockDim.x) {
         float y = t * freqs[i];
         sh[i] = sinf(y) * 1.41421356237309515f;
         sh[half + i] = cosf(y) * 1.41421356237309515f;
     }
-    for (int i = threadIdx.x; i < cond_dim; i += blockDim.x) sh[2 * half + i] = cond[(size_t)tile * cond_dim + i];
+    for (int c = 0; c < d.n; ++c) {
+        const float* xr = cond + (size_t)tile * d.row_len + d.xoff[c];
+        for (int i = threadIdx.x; i < d.dims[c]; i += blockDim.x) {
+            float v;
+            if (d.type[c] == 0) v = xr[i];
+            else v = cosf(__fadd_rn(__fmul_rn(xr[0], fourier[d.froff[c] + i]), fourier[d.froff[c] + d.dims[c] + i])) * 1.41421356237309515f;  // mul then add, separately rounded like x.outer(freqs) + phases (|y| reaches ~50: an FMA would move cos by ~1e-6)
+            sh[nd + d.foff[c] + i] = v;
+        }
+    }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nd = 2 * half;
-    const float inv_norm = 1.f / sqrtf(1.f + (cond_dim > 0 ? cond_weight * cond_weight : 0.f));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int j = wave; j < emb_ch; j += blockDim.x / 64) {
         float a = 0.f;
         for (int k = lane; k < nd; k += 64) a += w_noise[(size_t)j * nd + k] * sh[k];
         a = wave_sum(a);
-        float b = 0.f;
-        if (cond_dim > 0) {
-            for (int k = lane; k < cond_dim; k += 64) b += w_cond[(size_t)j * cond_dim + k] * sh[nd + k];
-            b = mp_silu_acc(wave_sum(b));
+        for (int c = 0; c < d.n; ++c) {
+            float b = 0.f;
+            const float* w = w_cond + d.woff[c] + (size_t)j * d.dims[c];
+            for (int k = lane; k < d.dims[c]; k += 64) b += w[k] * sh[nd + d.foff[c] + k];
+            b = wave_sum(b);
+            if (d.type[c] == 0) b = mp_silu_acc(b);
+            a += d.weight[c] * b;
         }
-        if (lane == 0) emb[(size_t)row * emb_ch + j] = mp_silu_acc((a + cond_weight * b) * inv_norm);
+        if (lane == 0) emb[(size_t)row * emb_ch + j] = mp_silu_acc(a * d.inv_norm);
     }
 }
 
@@ -151,13 +170,22 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ qkv, T*
 
 // ------------------------------------------------------------------------------------------------ layout / scheduler
 // x: planar fp32 [N][C][HW]; xin: NHWC T [N][HW][cstride] = (x*scale, 1, 0...) — edm_unet.py:168 ones channel.
+// `ones_idx` = in_channels: the bias-surrogate channel sits after ALL input channels (sample + conditioning image).
 template <typename T>
-__global__ void prep_input_kernel(const float* __restrict__ x, T* __restrict__ xin, int N, int C, int HW, int cstride, float scale) {
+__global__ void prep_input_kernel(const float* __restrict__ x, T* __restrict__ xin, int N, int C, int HW, int cstride, float scale, int ones_idx) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)N * HW) return;
     int n = (int)(i / HW), p = (int)(i % HW);
     for (int c = 0; c < C; ++c) xin[i * cstride + c] = (T)(x[((size_t)n * C + c) * HW + p] * scale);
-    xin[i * cstride + C] = (T)1.f;
+    xin[i * cstride + ones_idx] = (T)1.f;
+}
+// conditioning-image channels of the model input (constant over the solver steps): xin[.., c0 + c] = img[n][c][p]
+template <typename T>
+__global__ void write_cond_img_kernel(const float* __restrict__ img, T* __restrict__ xin, int N, int Cc, int HW, int cstride, int c0) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * HW) return;
+    int n = (int)(i / HW), p = (int)(i % HW);
+    for (int c = 0; c < Cc; ++c) xin[i * cstride + c0 + c] = (T)img[((size_t)n * Cc + c) * HW + p];
 }
 
 // F: NHWC fp32 [N][HW][fstride] -> planar [N][C][HW]
@@ -197,7 +225,7 @@ __global__ void dpm_step_kernel(float* __restrict__ x, float* __restrict__ m1, c
 // pre:  x_t = cos t * sample + sin t * sigma_d * z ; xin = x_t / sigma_d ;  post: out = cos t * x_t - sin t * sigma_d * (-F)
 template <typename T>
 __global__ void consistency_pre_kernel(const float* __restrict__ sample, const float* __restrict__ z, float* __restrict__ xt, T* __restrict__ xin,
-                                       int N, int C, int HW, int cstride, float cos_t, float sin_t, float sigma_data) {
+                                       int N, int C, int HW, int cstride, float cos_t, float sin_t, float sigma_data, int ones_idx) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)N * HW) return;
     int n = (int)(i / HW), p = (int)(i % HW);
@@ -207,7 +235,7 @@ __global__ void consistency_pre_kernel(const float* __restrict__ sample, const f
         xt[xi] = v;
         xin[i * cstride + c] = (T)(v / sigma_data);
     }
-    xin[i * cstride + C] = (T)1.f;
+    xin[i * cstride + ones_idx] = (T)1.f;
 }
 __global__ void consistency_post_kernel(const float* __restrict__ xt, const float* __restrict__ F, float* __restrict__ out, int N, int C, int HW,
                                         int fstride, float cos_t, float sin_t, float sigma_data) {
@@ -367,11 +395,13 @@ __global__ void window_extract_kernel(const float* __restrict__ img, float* __re
 // explicit instantiations used by the engine
 template __global__ void attn_kernel<float>(const float*, float*, int, int);
 template __global__ void attn_kernel<__bf16>(const __bf16*, __bf16*, int, int);
-template __global__ void prep_input_kernel<float>(const float*, float*, int, int, int, int, float);
-template __global__ void prep_input_kernel<__bf16>(const float*, __bf16*, int, int, int, int, float);
+template __global__ void prep_input_kernel<float>(const float*, float*, int, int, int, int, float, int);
+template __global__ void prep_input_kernel<__bf16>(const float*, __bf16*, int, int, int, int, float, int);
+template __global__ void write_cond_img_kernel<float>(const float*, float*, int, int, int, int, int);
+template __global__ void write_cond_img_kernel<__bf16>(const float*, __bf16*, int, int, int, int, int);
 template __global__ void dpm_step_kernel<float>(float*, float*, const float*, float*, int, int, int, int, int, SchedCoef);
 template __global__ void dpm_step_kernel<__bf16>(float*, float*, const float*, __bf16*, int, int, int, int, int, SchedCoef);
-template __global__ void consistency_pre_kernel<float>(const float*, const float*, float*, float*, int, int, int, int, float, float, float);
-template __global__ void consistency_pre_kernel<__bf16>(const float*, const float*, float*, __bf16*, int, int, int, int, float, float, float);
+template __global__ void consistency_pre_kernel<float>(const float*, const float*, float*, float*, int, int, int, int, float, float, float, int);
+template __global__ void consistency_pre_kernel<__bf16>(const float*, const float*, float*, __bf16*, int, int, int, int, float, float, float, int);
 
 }  // namespace td

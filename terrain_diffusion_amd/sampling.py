@@ -79,13 +79,28 @@ def blend_normalize(engine, canvas, scale=1.0):
 
 
 @torch.no_grad()
-def sample_tiles_edm(model, scheduler, x, cond, steps):
-    """Runs `steps` DPM-Solver++ steps on a batch of independent tiles (device tensor x: [n,C,H,W], scaled noise). In place."""
+def sample_tiles_edm(model, scheduler, x, cond, steps, cond_img=None):
+    """Runs `steps` DPM-Solver++ steps on a batch of independent tiles (device tensor x: [n,C,H,W], scaled noise). In place.
+    cond_img: optional [n,Cc,H,W] conditioning-image channels concatenated after the sample channels in the model input
+    (coarse stage: world_pipeline.py:946 `torch.cat([scaled_in, cond_img], dim=1)`)."""
     scheduler.set_timesteps(steps)
     sig = scheduler.sigmas.to(torch.float32).cpu().contiguous()
     n, _, H, W = x.shape
-    check(lib().td_sample_edm(model._h, n, H, W, steps, ptr(sig), float(scheduler.config.sigma_data), ptr(cond), ptr(x)))
+    cimg = 0 if cond_img is None else cond_img.shape[1]
+    check(lib().td_sample_edm_img(model._h, n, H, W, steps, ptr(sig), float(scheduler.config.sigma_data), ptr(cond), ptr(cond_img), cimg, ptr(x)))
     return x
+
+
+@torch.no_grad()
+def consistency_step(model, t, sigma_data, sample, z, cond=None, cond_img=None):
+    """One trig-flow consistency step on a batch of tiles (world_pipeline.py:1097-1129 latent stage, :1229-1239 decoder):
+    x_t = cos t * sample + sin t * sigma_d * z ; out = cos t * x_t + sin t * sigma_d * model([x_t/sigma_d | cond_img], t, cond).
+    sample may be None (zeros).  Returns a new device tensor shaped like z."""
+    n, _, H, W = z.shape
+    out = torch.empty_like(z)
+    cimg = 0 if cond_img is None else cond_img.shape[1]
+    check(lib().td_sample_consistency_img(model._h, n, H, W, float(t), float(sigma_data), ptr(sample), ptr(z), ptr(cond), ptr(cond_img), cimg, ptr(out)))
+    return out
 
 
 @torch.no_grad()

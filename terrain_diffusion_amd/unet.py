@@ -29,8 +29,8 @@ class EDMUnet2D:
         mults = list(model_channel_mults or [1, 2, 3, 4])
         lpb = [layers_per_block] * len(mults) if isinstance(layers_per_block, int) else list(layers_per_block)
         conds = [list(c) for c in conditional_inputs]
-        if len(conds) > 1 or (conds and conds[0][0] != "tensor"):
-            raise NotImplementedError("one ['tensor', dim, weight] conditional input (base model) is supported")
+        if len(conds) > 8 or any(c[0] not in ("tensor", "float") for c in conds):
+            raise NotImplementedError("conditional inputs: up to 8 of type 'tensor' / 'float' ('embedding' tables are not on the accelerated path)")
         self.config = dict(image_size=image_size, in_channels=in_channels, out_channels=out_channels or in_channels,
                            model_channels=model_channels, model_channel_mults=mults, layers_per_block=lpb,
                            emb_channels=emb_channels, noise_emb_dims=noise_emb_dims, attn_resolutions=list(attn_resolutions or []),
@@ -53,8 +53,11 @@ class EDMUnet2D:
         cfg.concat_balance = float(concat_balance)
         cfg.noise_emb_dims = int(noise_emb_dims or 0)
         cfg.emb_channels = int(emb_channels or 0)
-        cfg.cond_dim = int(conds[0][1]) if conds else 0
-        cfg.cond_weight = float(conds[0][2]) if conds else 0.0
+        cfg.n_cond = len(conds)
+        for i, (typ, dim, wt) in enumerate(conds):
+            cfg.cond_type[i] = 0 if typ == "tensor" else 1
+            cfg.cond_dims[i] = int(dim)
+            cfg.cond_weights[i] = float(wt)
         self._h = C.c_void_p()
         check(lib().td_unet_create(self.engine._h, C.byref(cfg), DTYPES[dtype], C.byref(self._h)))
         self._finalized = False
@@ -133,12 +136,32 @@ class EDMUnet2D:
         t = f32(noise_labels, "cpu").flatten()
         if t.numel() == 1 and n > 1:
             t = t.expand(n).contiguous()
-        cond = f32(conditional_inputs[0]) if conditional_inputs else None
+        cond = self.cond_rows(conditional_inputs, n, x.device)
         out = torch.empty((n, self.config["out_channels"], H, W), dtype=torch.float32, device=x.device)
         check(lib().td_unet_forward(self._h, n, H, W, ptr(x), ptr(t), ptr(cond), ptr(out)))
         return out
 
     forward = __call__
+
+    def cond_rows(self, conditional_inputs, n, device=None):
+        """conditional_inputs (list, reference order: (n,dim) tensors for 'tensor' inputs, (n,) or (1,) for 'float' inputs)
+        -> one contiguous (n, row_len) fp32 conditioning matrix as the C-ABI takes it, or None."""
+        conds = self.config["conditional_inputs"]
+        conditional_inputs = list(conditional_inputs or [])
+        if len(conditional_inputs) != len(conds):
+            raise ValueError("Invalid number of conditional inputs")
+        if not conds:
+            return None
+        cols = []
+        for (typ, dim, _w), v in zip(conds, conditional_inputs):
+            v = torch.as_tensor(v, dtype=torch.float32)
+            if typ == "tensor":
+                v = v.reshape(-1, dim)
+            else:
+                v = v.reshape(-1, 1)
+            cols.append(v.expand(n, -1) if v.shape[0] == 1 else v)
+        out = torch.cat([c.to(cols[0].device) for c in cols], dim=1).contiguous()
+        return out.to(device) if device is not None else out
 
     def read_activation(self, n, H, W, label, max_elems=1 << 26):
         """Debug/test: output of fused conv op `label` from the last forward with this (n,H,W), as NCHW fp32 (host)."""

@@ -306,7 +306,29 @@ def gen_sampling():
     save("sampling", **out)
 
 
-ALL = dict(rng=gen_rng, geometry=gen_geometry, schedule=gen_schedule, unet=gen_unet, sampling=gen_sampling)
+def gen_stages():
+    """EDMUnet2D in its other two pipeline roles: coarse model (5 'float' conditional inputs through MPFourier,
+    11 -> 6 channels) and decoder (no conditional inputs, 5 -> 1 channels), full-size configs at 64x64 input."""
+    from oracle import rng
+    from oracle.unet import COARSE_CONFIG, DECODER_CONFIG, synth_state_dict
+    out = {}
+    cfgc = dict(COARSE_CONFIG)
+    mc = _ref_model(cfgc, synth_state_dict(cfgc, seed=4321))
+    x = torch.from_numpy(rng.standard_normal(41, (2, 11, 64, 64)))
+    conds = [torch.from_numpy(rng.standard_normal(50 + i, (2,))) for i in range(5)]
+    with torch.no_grad():
+        out["coarse_out"] = mc(x, noise_labels=torch.tensor([1.3, 0.4]), conditional_inputs=conds).numpy()
+        out["coarse_emb"] = mc.compute_embeddings(torch.tensor([1.3, 0.4]), conds).numpy()
+    cfgd = dict(DECODER_CONFIG)
+    md = _ref_model(cfgd, synth_state_dict(cfgd, seed=2468))
+    xd = torch.from_numpy(rng.standard_normal(43, (1, 5, 64, 64)))
+    with torch.no_grad():
+        out["decoder_out"] = md(xd, noise_labels=torch.tensor([1.5]), conditional_inputs=[]).numpy()
+    print("coarse rms", float(np.sqrt((out["coarse_out"] ** 2).mean())), "decoder rms", float(np.sqrt((out["decoder_out"] ** 2).mean())))
+    save("stages", **out)
+
+
+ALL = dict(stages=gen_stages, rng=gen_rng, geometry=gen_geometry, schedule=gen_schedule, unet=gen_unet, sampling=gen_sampling)
 
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden generation needs the reference checkout"

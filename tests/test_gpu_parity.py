@@ -419,3 +419,71 @@ def test_infinite_latent_stage_vs_oracle(td, orc):
     exp = acc[:-1] / acc[-1:]
     assert rel_rms(got.numpy(), exp.numpy()) < 1e-5
     m.close()
+
+
+# ------------------------------------------------------------------------------------------- coarse / decoder roles
+@pytest.mark.parametrize("dtype,tol", [("fp32", 5e-6), ("bf16", 2e-2)])
+def test_coarse_and_decoder_forward(td, orc, golden, dtype, tol):
+    from oracle.unet import COARSE_CONFIG, DECODER_CONFIG
+    g = golden("stages")
+    mc = td.EDMUnet2D(**COARSE_CONFIG, dtype=dtype).load_state_dict(orc["unet"].synth_state_dict(COARSE_CONFIG, seed=4321))
+    x = torch.from_numpy(orc["rng"].standard_normal(41, (2, 11, 64, 64))).cuda()
+    conds = [torch.from_numpy(orc["rng"].standard_normal(50 + i, (2,))) for i in range(5)]
+    y = mc(x, torch.tensor([1.3, 0.4]), conds)
+    assert y.shape == (2, 6, 64, 64) and rel_rms(y.cpu().numpy(), g["coarse_out"]) < tol
+    if dtype == "fp32":
+        assert rel_rms(mc.read_activation(2, 64, 64, "@emb").reshape(2, -1).numpy(), g["coarse_emb"]) < 5e-6
+    mc.close()
+    md = td.EDMUnet2D(**DECODER_CONFIG, dtype=dtype).load_state_dict(orc["unet"].synth_state_dict(DECODER_CONFIG, seed=2468))
+    xd = torch.from_numpy(orc["rng"].standard_normal(43, (1, 5, 64, 64))).cuda()
+    yd = md(xd, torch.tensor([1.5]), [])
+    assert yd.shape == (1, 1, 64, 64) and rel_rms(yd.cpu().numpy(), g["decoder_out"]) < tol
+    md.close()
+
+
+def test_coarse_stage_loop_and_decoder_step_vs_oracle(td, orc):
+    """The per-tile arithmetic of _coarse_inference (world_pipeline.py:928-951: 6 sample + 5 conditioning-image channels, 20-step
+    DPM-Solver++ loop) and of _decoder_inference (world_pipeline.py:1221-1241: 1 sample + 4 upsampled-latent channels, one
+    trig-flow step) through td_sample_edm_img / td_sample_consistency_img vs the oracle U-Net + oracle solver (fp32, 1e-5)."""
+    from oracle.unet import COARSE_CONFIG, DECODER_CONFIG
+    from oracle import schedule
+    from terrain_diffusion_amd.sampling import sample_tiles_edm, consistency_step
+    rng_, U = orc["rng"], orc["unet"]
+    # ---- coarse
+    sdc = U.synth_state_dict(COARSE_CONFIG, seed=4321)
+    mc = td.EDMUnet2D(**COARSE_CONFIG, dtype="fp32").load_state_dict(sdc)
+    oc = U.OracleUnet(COARSE_CONFIG, sdc)
+    n, S, steps = 2, 16, 20
+    sch = td.EDMDPMSolverMultistepScheduler()
+    sch.set_timesteps(steps)
+    cond_img = torch.from_numpy(rng_.standard_normal(61, (n, 5, S, S)))
+    conds = [torch.full((n,), float(np.log(np.tan(np.arctan(0.5 + 0.1 * i)) / 8.0))) for i in range(5)]
+    x0 = torch.from_numpy(rng_.standard_normal(62, (n, 6, S, S))) * sch.sigmas[0]
+    x = x0.clone().cuda()
+    sample_tiles_edm(mc, sch, x, mc.cond_rows(conds, n, "cuda"), steps, cond_img=cond_img.cuda().contiguous())
+    sig, orders = schedule.karras_sigmas(steps)[0], schedule.solver_orders(steps)
+    xr, m_prev = x0.clone(), None
+    with torch.no_grad():
+        for i in range(steps):
+            xin = torch.cat([schedule.precondition_inputs(xr, sig[i]), cond_img], dim=1)
+            F_ = oc(xin, schedule.trigflow_t(sig[i].view(-1).expand(n)), conds)
+            xr, m_prev = schedule.dpm_step(sig, i, orders[i], xr, F_, m_prev)
+    assert rel_rms(x.cpu().numpy(), xr.numpy()) < 1e-5
+    mc.close()
+    # ---- decoder
+    sdd = U.synth_state_dict(DECODER_CONFIG, seed=2468)
+    md = td.EDMUnet2D(**DECODER_CONFIG, dtype="fp32").load_state_dict(sdd)
+    od = U.OracleUnet(DECODER_CONFIG, sdd)
+    T = 64
+    lat = torch.from_numpy(rng_.standard_normal(71, (1, 4, T // 8, T // 8)))
+    up = torch.nn.functional.interpolate(lat, size=(T, T), mode="nearest")                       # world_pipeline.py:1224-1226
+    z = torch.from_numpy(rng_.gaussian_noise_patch(42 + 5819, 3 * 48, -2 * 48, T, T, 1, T, T))[None]
+    t = float(torch.atan(torch.tensor(80.0) / 0.5))
+    out = consistency_step(md, t, 0.5, None, z.cuda().contiguous(), cond=None, cond_img=up.cuda().contiguous())
+    with torch.no_grad():
+        tt = torch.tensor(t)
+        x_t = torch.cos(tt) * torch.zeros(1, 1, T, T) + torch.sin(tt) * (z * 0.5)
+        pred = -od(torch.cat([x_t / 0.5, up], dim=1), tt.view(1), [])
+        ref = torch.cos(tt) * x_t - torch.sin(tt) * 0.5 * pred
+    assert rel_rms(out.cpu().numpy(), ref.numpy()) < 1e-5
+    md.close()

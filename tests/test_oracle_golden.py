@@ -205,3 +205,19 @@ def test_base_tile_20_steps(golden):
     m = OracleUnet(BASE_CONFIG, synth_state_dict(BASE_CONFIG, seed=1234))
     y = tiling.sample_base_diffusion_tiled(m, (1, 5, 64, 64), tiling.synthetic_cond_grid(1, 1), steps=20, tile_size=64)
     assert rel_rms(y.numpy(), g["base_tile_steps20"]) < 2e-5
+
+
+def test_coarse_and_decoder_models_vs_reference(golden):
+    """EDMUnet2D in its coarse ('float' conditional inputs via MPFourier) and decoder (no conditioning) roles — 5e-6 rel-RMS."""
+    from oracle.unet import COARSE_CONFIG, DECODER_CONFIG
+    g = golden("stages")
+    mc = OracleUnet(COARSE_CONFIG, synth_state_dict(COARSE_CONFIG, seed=4321))
+    x = torch.from_numpy(rng.standard_normal(41, (2, 11, 64, 64)))
+    conds = [torch.from_numpy(rng.standard_normal(50 + i, (2,))) for i in range(5)]
+    with torch.no_grad():
+        assert rel_rms(mc.embeddings(torch.tensor([1.3, 0.4]), conds).numpy(), g["coarse_emb"]) < 5e-6
+        assert rel_rms(mc(x, torch.tensor([1.3, 0.4]), conds).numpy(), g["coarse_out"]) < 5e-6
+    md = OracleUnet(DECODER_CONFIG, synth_state_dict(DECODER_CONFIG, seed=2468))
+    xd = torch.from_numpy(rng.standard_normal(43, (1, 5, 64, 64)))
+    with torch.no_grad():
+        assert rel_rms(md(xd, torch.tensor([1.5]), []).numpy(), g["decoder_out"]) < 5e-6
