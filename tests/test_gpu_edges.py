@@ -1,0 +1,153 @@
+"""GPU: edge cases, error behaviour of the C-ABI surface, and size-independent properties at BASELINE sizes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def td():
+    import terrain_diffusion_amd as t
+    return t
+
+
+@pytest.fixture(scope="module")
+def tiny(td):
+    from oracle.unet import synth_state_dict, tiny_config
+    cfg = tiny_config(64, 1)
+    m = td.EDMUnet2D(**cfg, dtype="bf16").load_state_dict(synth_state_dict(cfg, seed=77))
+    yield m, cfg
+    m.close()
+
+
+def test_api_misuse_fails_loudly(td, tiny):
+    from oracle.unet import synth_state_dict, tiny_config
+    from terrain_diffusion_amd._lib import lib
+    m, cfg = tiny
+    fresh = td.EDMUnet2D(**cfg, dtype="bf16")
+    with pytest.raises(RuntimeError):                                   # forward before weights
+        fresh(torch.zeros(1, 5, 16, 16), torch.tensor([1.0]), [torch.zeros(1, 58)])
+    sd = synth_state_dict(cfg, seed=77)
+    bad = dict(sd); bad.pop("out_gain")
+    with pytest.raises(KeyError):                                       # missing parameter
+        fresh.load_state_dict(bad)
+    bad = dict(sd); bad["enc.512x512_conv.weight"] = torch.zeros(64, 6, 3, 2)
+    with pytest.raises(ValueError):                                     # wrong shape
+        fresh.load_state_dict(bad)
+    assert lib().td_unet_set_param(fresh._h, b"no.such.param", None, 0) != 0 and b"unknown parameter" in lib().td_last_error()
+    fresh.close()
+    with pytest.raises(td.TdError):                                     # H, W must be divisible by 2^(levels-1)
+        m(torch.zeros(1, 5, 12, 12).cuda(), torch.tensor([1.0]), [torch.zeros(1, 58).cuda()])
+    with pytest.raises(ValueError):                                     # wrong number of conditional inputs
+        m(torch.zeros(1, 5, 16, 16).cuda(), torch.tensor([1.0]), [])
+    with pytest.raises(NotImplementedError):                            # unsupported constructor options say so
+        td.EDMUnet2D(**{**cfg, "fourier_scale": 1})
+    with pytest.raises(NotImplementedError):
+        td.EDMDPMSolverMultistepScheduler(algorithm_type="sde-dpmsolver++")
+    with pytest.raises(td.TdError):                                     # window larger than the noise tile
+        td.gaussian_noise_patches(1, [(0, 0)], 65, 64, channels=1, tile_h=64, tile_w=64)
+    assert td.gaussian_noise_patches(1, [], 8, 8).shape[0] == 0        # empty batch is a no-op
+    assert td.standard_normal(5, (0,)).size == 0
+
+
+def test_degenerate_sizes(td, tiny):
+    """1-step and 2-step schedules, canvas == tile, canvas smaller than 2 tiles, untiled path, batch of 1 window."""
+    from oracle import tiling
+    from oracle.unet import OracleUnet, synth_state_dict
+    m, cfg = tiny
+    om = OracleUnet(cfg, synth_state_dict(cfg, seed=77))
+    sch = td.EDMDPMSolverMultistepScheduler()
+    kw = dict(cond_means=torch.zeros(7), cond_stds=torch.ones(7), noise_level=torch.tensor(0.0), histogram_raw=torch.zeros(1, 5))
+    for H, W, steps in [(16, 16, 1), (16, 16, 2), (16, 24, 3), (16, 17, 2)]:
+        cond = tiling.synthetic_cond_grid(len(tiling.tile_starts(H, 16, 8)), len(tiling.tile_starts(W, 16, 8)))
+        y = td.sample_base_diffusion(m, sch, (1, 5, H, W), cond, steps=steps, tile_size=16, noise_seed=3, **kw)
+        ref = tiling.sample_base_diffusion_tiled(om, (1, 5, H, W), cond, steps=steps, tile_size=16, noise_seed=3)
+        assert y.shape == (1, 5, H, W) and rel_rms(y.cpu().numpy(), ref.numpy()) < 2e-2, (H, W, steps)
+    # untiled path returns the raw sample like the reference's `return samples` (sample_diffusion_base.py:113)
+    c58 = tiling.process_cond_img(tiling.synthetic_cond_grid(1, 1), torch.zeros(1, 5), torch.zeros(7), torch.ones(7), 0.0)[0]
+    y = td.sample_base_diffusion(m, sch, (1, 5, 16, 16), c58, steps=2, tile_size=None, noise_seed=3, **kw)
+    assert y.shape == (1, 5, 16, 16) and torch.isfinite(y).all()
+
+
+def test_determinism_and_seed_sensitivity(td, tiny):
+    """same (seed, coordinates) -> bit-identical output on repeat; different seed or origin -> different output; a window's
+    result does not depend on where it sits in the batch."""
+    m, _ = tiny
+    sch = td.EDMDPMSolverMultistepScheduler()
+    cond = torch.zeros(3, 58)
+    a = td.sample_independent_tiles(m, sch, [(0, 0), (64, 64), (-128, 32)], cond, steps=4, tile_size=16, noise_seed=9)
+    b = td.sample_independent_tiles(m, sch, [(0, 0), (64, 64), (-128, 32)], cond, steps=4, tile_size=16, noise_seed=9)
+    assert torch.equal(a, b)
+    c = td.sample_independent_tiles(m, sch, [(-128, 32), (0, 0), (64, 64)], cond, steps=4, tile_size=16, noise_seed=9)
+    assert torch.equal(c[1], a[0]) and torch.equal(c[0], a[2])
+    d = td.sample_independent_tiles(m, sch, [(0, 0)], cond[:1], steps=4, tile_size=16, noise_seed=10)
+    assert not torch.equal(d[0], a[0])
+    assert not torch.equal(a[0], a[1])
+
+
+def test_noise_field_properties_full_size(td):
+    """BASELINE-size noise (5x64x64 per window, 64 windows of an 8x8 grid at stride 32): every overlap agrees bit-for-bit,
+    moments are those of N(0,1), and the field is translation-consistent (window at (y,x) == crop of a bigger window)."""
+    origins = [(32 * i, 32 * j) for i in range(8) for j in range(8)]
+    w = td.gaussian_noise_patches(42 + 5819, origins, 64, 64, channels=5, tile_h=64, tile_w=64)
+    g = w.view(8, 8, 5, 64, 64)
+    assert torch.equal(g[:, :-1, :, :, 32:], g[:, 1:, :, :, :32]) and torch.equal(g[:-1, :, :, 32:, :], g[1:, :, :, :32, :])
+    assert abs(float(w.mean())) < 5e-3 and abs(float(w.std()) - 1.0) < 5e-3
+    big = td.gaussian_noise_patches(42 + 5819, [(0, 0)], 64, 64, channels=5, tile_h=64, tile_w=64)
+    assert torch.equal(big[0], g[0, 0])
+    neg = td.gaussian_noise_patches(7, [(-64, -64), (-32, -32)], 64, 64, channels=2, tile_h=64, tile_w=64)
+    assert torch.equal(neg[0][:, 32:, 32:], neg[1][:, :32, :32])
+
+
+def test_blend_linearity_and_partition_of_unity_full_size(td):
+    """overlap blend at BASELINE config-3 size (8x8 windows of 64 on a 288x288 canvas): linear in the tiles, reproduces a constant,
+    and the interior weight sum equals the analytic constant (2 - 0.999*32/31.5)^2."""
+    from terrain_diffusion_amd.engine import get_engine
+    from terrain_diffusion_amd.sampling import blend_windows, blend_normalize, _tile_starts
+    eng = get_engine("cuda")
+    hs = ws = _tile_starts(288, 64, 32)
+    idx = [(i, j) for i in range(8) for j in range(8)]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    A = torch.randn(64, 5, 64, 64, device="cuda", generator=g)
+    B = torch.randn(64, 5, 64, 64, device="cuda", generator=g)
+
+    def blend(t):
+        c = torch.zeros(6, 288, 288, device="cuda")
+        blend_windows(eng, c, t.contiguous(), idx, hs, ws, 64)
+        return c
+    ca, cb, cab = blend(A), blend(B), blend(2 * A - 3 * B)
+    assert torch.allclose(cab[:5], 2 * ca[:5] - 3 * cb[:5], rtol=1e-4, atol=1e-4)
+    assert torch.equal(ca[5], cb[5])
+    const = (2 - 0.999 * 32 / 31.5) ** 2
+    assert torch.allclose(ca[5][32:256, 32:256], torch.full((224, 224), const, device="cuda"), atol=1e-5)
+    ones = blend_normalize(eng, blend(torch.ones_like(A)), 1.0)
+    assert torch.allclose(ones, torch.ones_like(ones), rtol=1e-6)
+    # accumulate in two launches == one launch (weights) and close for values
+    c2 = torch.zeros(6, 288, 288, device="cuda")
+    blend_windows(eng, c2, A[:32].contiguous(), idx[:32], hs, ws, 64)
+    blend_windows(eng, c2, A[32:].contiguous(), idx[32:], hs, ws, 64, accumulate=True)
+    assert torch.allclose(c2, ca, rtol=1e-5, atol=1e-5)
+
+
+def test_unet_linearity_in_out_gain_and_clip_range(td):
+    """property of the network maths that does not need the oracle: the output scales linearly with out_gain, and stays finite for
+    extreme inputs (activations are clipped at +-256 inside every block)."""
+    from oracle.unet import synth_state_dict, tiny_config
+    cfg = tiny_config(64, 1)
+    sd = synth_state_dict(cfg, seed=5)
+    x = torch.randn(1, 5, 16, 16).cuda()
+    c = torch.randn(1, 58).cuda()
+    outs = []
+    for gain in (1.0, 2.5):
+        sd["out_gain"] = torch.tensor(gain)
+        m = td.EDMUnet2D(**cfg, dtype="fp32").load_state_dict(sd)
+        outs.append(m(x, torch.tensor([0.8]), [c]))
+        big = m(x * 1e4, torch.tensor([1.5]), [c * 50])
+        assert torch.isfinite(big).all()
+        m.close()
+    assert rel_rms((outs[1] / 2.5).cpu().numpy(), outs[0].cpu().numpy()) < 1e-6
