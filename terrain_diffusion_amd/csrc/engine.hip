@@ -335,7 +335,8 @@ static int pack_conv(td_unet* u, ConvWeights& cw) {
                     }
     }
     cw.packed.reset(new DevBuf());
-    HIP_TRY(cw.packed->alloc(total * u->esize() + 8192, true));  // tail padding: the LDS-DMA kernel may over-read 32 rows
+    // tail padding: the LDS-DMA kernel over-reads 32 rows per tile and always fetches two K-steps past the end
+    HIP_TRY(cw.packed->alloc(total * u->esize() + 2 * (size_t)cw.cout_pad * 128 + 16384, true));
     HIP_TRY(hipMemcpy(cw.packed->p, u->bf16 ? (const void*)stage16.data() : (const void*)stage.data(), total * u->esize(), hipMemcpyHostToDevice));
     return TD_OK;
 }

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 #include "conv_igemm.hip"
 #include "conv_glds.hip"
 using namespace td;
@@ -13,24 +14,31 @@ using namespace td;
 int main(int argc, char** argv) {
     int N = argc > 1 ? atoi(argv[1]) : 64, H = argc > 2 ? atoi(argv[2]) : 64, W = argc > 3 ? atoi(argv[3]) : 64;
     int Cin = argc > 4 ? atoi(argv[4]) : 192, Cout = argc > 5 ? atoi(argv[5]) : 192, taps = argc > 6 ? atoi(argv[6]) : 9;
-    int xform = argc > 7 ? atoi(argv[7]) : 0, bn = argc > 8 ? atoi(argv[8]) : 64, ksplit = argc > 9 ? atoi(argv[9]) : 1, flavor = argc > 10 ? atoi(argv[10]) : 0;
+    int xform = argc > 7 ? atoi(argv[7]) : 0, bn = argc > 8 ? atoi(argv[8]) : 64, ksplit = argc > 9 ? atoi(argv[9]) : 1, flavor = argc > 10 ? atoi(argv[10]) : 0, epi = argc > 11 ? atoi(argv[11]) : 0;
     const int chunk = 64;
     size_t M = (size_t)N * H * W;
     int kgroups = Cin / chunk, ksteps = kgroups * taps;
     void *x, *w, *out; float* partial = nullptr;
-    CK(hipMalloc(&x, M * Cin * 2)); CK(hipMalloc(&w, (size_t)ksteps * Cout * 128 + 8192)); CK(hipMalloc(&out, M * Cout * 2));
+    CK(hipMalloc(&x, M * Cin * 2)); CK(hipMalloc(&w, (size_t)(ksteps + 2) * Cout * 128 + 16384)); CK(hipMalloc(&out, M * Cout * 2));
     std::vector<uint16_t> hx(M * Cin), hw((size_t)ksteps * Cout * 64);
     srand(1);
     for (auto& v : hx) v = 0x3f00 + (rand() & 0xff) + ((rand() & 1) << 15);          // ~ +-0.5..1
     for (auto& v : hw) v = 0x3c00 + (rand() & 0xff) + ((rand() & 1) << 15);          // small
     CK(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
     if (ksplit > 1) CK(hipMalloc(&partial, (size_t)ksplit * M * Cout * 4));
+#ifdef TD_TRACE
+    const size_t trace_n = (size_t)65536 * 8 * 8;
+    CK(hipMalloc(&partial, trace_n * 8)); CK(hipMemset(partial, 0, trace_n * 8));
+#endif
     ConvParams p; memset(&p, 0, sizeof p);
     p.nseg = 1; p.seg[0].src = x; p.seg[0].C = Cin; p.seg[0].cstride = Cin; p.seg[0].Hs = H; p.seg[0].Ws = W; p.seg[0].taps = taps; p.seg[0].xform = xform; p.seg[0].scale = 1.f;
     p.wpack = w; p.N = N; p.H = H; p.W = W; p.Cout = Cout; p.CoutPad = Cout; p.kgroups = kgroups; p.ksplit = ksplit; p.partial = partial;
     bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? (flavor == 2 ? 4 : 2) : 1; int TH = (flavor == 2 && !narrow) ? 16 : 8;
     p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH; p.img_groups = (N + NIMG - 1) / NIMG; p.n_ntiles = Cout / bn;
-    p.epi = EPI_PLAIN; p.out = out; p.out_cstride = Cout;
+    p.epi = epi; p.out = out; p.out_cstride = Cout;
+    if (epi == EPI_EMB_SILU) { float* cv; CK(hipMalloc(&cv, (size_t)N * Cout * 4)); std::vector<float> hc((size_t)N * Cout, 1.01f); CK(hipMemcpy(cv, hc.data(), hc.size() * 4, hipMemcpyHostToDevice)); p.cvec = cv; p.cvec_stride = Cout; }
+    if (epi == EPI_RESIDUAL) { void* r; float* ssq; CK(hipMalloc(&r, M * Cout * 2)); CK(hipMemcpy(r, hx.data(), std::min(hx.size(), M * Cout) * 2, hipMemcpyHostToDevice)); CK(hipMalloc(&ssq, M * 8 * 4)); CK(hipMemset(ssq, 0, M * 8 * 4));
+        p.res = r; p.res_cstride = Cout; p.res_Hs = H; p.res_Ws = W; p.res_scale = 0.9f; p.clip = 256.f; p.out_sumsq = ssq; }
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) CK((flavor >= 2 ? launch_conv_glds(p, narrow, bn, flavor - 2, st) : launch_conv(p, true, narrow, bn, flavor, st)));
@@ -41,7 +49,20 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     double flop = 2.0 * M * Cout * Cin * taps;
-    printf("N%d %dx%d Cin%d Cout%d taps%d xform%d bn%d ks%d fl%d : %.1f us  %.1f TFLOP/s (%.1f%% of 2500)  wgs=%d\n", N, H, W, Cin, Cout, taps, xform, bn, ksplit, flavor, ms * 1e3,
+    printf("N%d %dx%d Cin%d Cout%d taps%d xform%d bn%d ks%d fl%d epi%d : %.1f us  %.1f TFLOP/s (%.1f%% of 2500)  wgs=%d\n", N, H, W, Cin, Cout, taps, xform, bn, ksplit, flavor, epi, ms * 1e3,
            flop / ms / 1e9, flop / ms / 1e9 / 25.0, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * ksplit);
+#ifdef TD_TRACE
+    {
+        const int wgs = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, nw = 8;
+        std::vector<unsigned long long> tb((size_t)wgs * nw * 8);
+        CK(hipMemcpy(tb.data(), partial, tb.size() * 8, hipMemcpyDeviceToHost));
+        double s[5] = {0, 0, 0, 0, 0}; unsigned long long t0 = ~0ull, t1 = 0;
+        for (int i = 0; i < wgs * nw; ++i) { for (int j = 0; j < 5; ++j) s[j] += (double)tb[(size_t)i * 8 + j]; if (tb[(size_t)i*8+5] && tb[(size_t)i*8+5] < t0) t0 = tb[(size_t)i*8+5]; if (tb[(size_t)i*8+6] > t1) t1 = tb[(size_t)i*8+6]; }
+        for (int j = 0; j < 5; ++j) s[j] /= (double)wgs * nw;
+        printf("  trace (s_memtime ticks, mean per wave): prologue %.0f  loop %.0f (of which tap-entry wait %.0f, restage %.0f, body %.0f)  epilogue %.0f  | WG total %.0f | kernel span %.0f ticks = %.2f ticks/us\n",
+               s[0], s[1], s[3], s[4], s[1] - s[3] - s[4], s[2], s[0] + s[1] + s[2], (double)(t1 - t0), (double)(t1 - t0) / (ms * 1e3));
+        printf("  taps per WG: %d  -> body %.0f ticks/tap, wait %.0f ticks/tap\n", ksteps, (s[1] - s[3] - s[4]) / ksteps, s[3] / ksteps);
+    }
+#endif
     return 0;
 }
