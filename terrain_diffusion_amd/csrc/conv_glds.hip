@@ -240,6 +240,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(co
             _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                \
                 acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WF[j_]), __builtin_bit_cast(bf16x8, XF[i_]), acc[i_][j_], 0, 0, 0); \
     }
+    // pin the issue order inside a tap to the source order (two k-steps of fragments in flight ahead of the MFMAs that use them);
+    // left alone, hipcc sinks the reads next to their consumers to save registers and exposes the LDS latency 4x per tap
+#ifdef TD_NO_SCHED
+#define TD_SCHED_TAP()
+#else
+#define TD_SCHED_TAP()                                                                                       \
+    {                                                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (NT + MT), 0);                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * NT, 0);                                         \
+    }
+#endif
     // PEND: the next group's A_ITERS patch loads were issued after the tile that is in flight (taps 1 and 2 of a 9-tap group);
     // vm ops retire in order, so "tile k has landed" == "at most <what was issued after it> is outstanding"
 #define TD_TAP(TAPIDX, SLOT, TOFF, PEND)                                                                     \
@@ -255,8 +270,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(co
             conservative vmcnt(0) for them lands where only a long-issued tile is in flight, not at the restage */ \
             _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) asm volatile("" : "+v"(av[it_]));      \
         }                                                                                                    \
-        TD_GLDS_B(((SLOT) + 2) % RING);                                                                      \
-        if ((TAPIDX) == 0 && has_next) TD_LOAD_A(chunk + 1);                                                 \
+        TD_ABL_BLOAD(TD_GLDS_B(((SLOT) + 2) % RING));                                                        \
+        TD_ABL_BSTORE(if ((TAPIDX) == 0 && has_next) TD_LOAD_A(chunk + 1));                                  \
         TD_FRAG_READ(wfA_, xfA_, SLOT, 0, TOFF);                                                             \
         TD_FRAG_READ(wfB_, xfB_, SLOT, 1, TOFF);                                                             \
         TD_FRAG_MFMA(wfA_, xfA_);                                                                            \
@@ -265,6 +280,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(co
         TD_FRAG_READ(wfB_, xfB_, SLOT, 3, TOFF);                                                             \
         TD_FRAG_MFMA(wfA_, xfA_);                                                                            \
         TD_FRAG_MFMA(wfB_, xfB_);                                                                            \
+        TD_SCHED_TAP();                                                                                      \
     }
     // 1x1 segment: one K-step per group.  The next group's patch loads go out first; the weight tile two steps ahead is fetched
     // AFTER the restage (whose compiler-inserted vmcnt(0) for the patch registers would otherwise drain a just-issued tile).
@@ -289,6 +305,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(co
         if (seg > 0) {  // first K-group of a later segment: its patch could not be prefetched (different source tensor / transform)
             TD_SEG_BEGIN(seg);
             TD_LOAD_A(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // every wave is done reading the previous patch
             asm volatile("" ::: "memory");
             TD_STORE_A();                  // visible after the next tap's lgkmcnt(0) + barrier
@@ -304,9 +321,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(co
             }
             if (has_next) {
                 TD_T(tS0_);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();  // every wave is done reading the current patch
                 asm volatile("" ::: "memory");
-                TD_STORE_A();                  // visible to the others after the next tap's lgkmcnt(0) + barrier
+                TD_ABL_BSTORE(TD_STORE_A());   // visible to the others after the next tap's lgkmcnt(0) + barrier
                 TD_T(tS1_); TD_TACC(tr_stage, tS0_, tS1_);
             }
             if (seg_taps != 9) {
@@ -318,6 +336,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(co
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two over-fetched tail tiles must not land in a successor's LDS
 #undef TD_TOFF
 #undef TD_TAP
+#undef TD_SCHED_TAP
 #undef TD_TAP1
 #undef TD_FRAG_READ
 #undef TD_FRAG_MFMA

@@ -151,3 +151,22 @@ def test_unet_linearity_in_out_gain_and_clip_range(td):
         assert torch.isfinite(big).all()
         m.close()
     assert rel_rms((outs[1] / 2.5).cpu().numpy(), outs[0].cpu().numpy()) < 1e-6
+
+
+def test_forward_bitwise_repeatable_under_load(td):
+    """race detector for the LDS-DMA ring / patch restage protocol: the full-size base U-Net (throughput kernels at every level for
+    batch 16) must give bit-identical outputs on 30 back-to-back runs, for both a batch and its permutation."""
+    from oracle.unet import BASE_CONFIG, synth_state_dict
+    m = td.EDMUnet2D(**BASE_CONFIG, dtype="bf16").load_state_dict(synth_state_dict(BASE_CONFIG, seed=3))
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(16, 5, 64, 64, device="cuda", generator=g)
+    c = torch.randn(16, 58, device="cuda", generator=g)
+    t = torch.linspace(-1.0, 1.5, 16)
+    ref = m(x, t, [c])
+    assert torch.isfinite(ref).all()
+    for _ in range(30):
+        assert torch.equal(m(x, t, [c]), ref)
+    perm = torch.arange(15, -1, -1, device="cuda")
+    out = m(x[perm].contiguous(), t[perm.cpu()].contiguous(), [c[perm].contiguous()])
+    assert torch.equal(out[perm], ref)
+    m.close()
