@@ -96,6 +96,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(co
     unsigned long long tr_wait = 0, tr_stage = 0;
 #endif
     TD_T(tr_start);
+#ifdef TD_TRACE
+    const unsigned long long tr_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     int bid = blockIdx.x;
     const int ntile = bid % p.n_ntiles; bid /= p.n_ntiles;
@@ -227,6 +230,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(co
     TD_STORE_A();
     TD_T(tr_pro);
 
+#define TD_TOFF(T) ((((T) / 3) * PW + ((T) % 3)) * PITCH)
     int slot = 0;  // ring slot of the current K-step; compile-time inside a 9-tap group (RING divides 9), tracked for 1x1 segments
     u32x4 wfA_[NT], xfA_[MT], wfB_[NT], xfB_[MT];
 #define TD_FRAG_READ(WF, XF, SLOT, KS, TOFF)                                                                 \
@@ -282,6 +286,52 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(co
         TD_FRAG_MFMA(wfB_, xfB_);                                                                            \
         TD_SCHED_TAP();                                                                                      \
     }
+    // Pipelined form (TD_PIPE): the tap's barrier sits between k-steps 1 and 2 and does NOT drain the LDS queue; the next tap's first
+    // two k-steps of fragments are requested behind this tap's last MFMAs, so no fragment read is ever waited for right after
+    // it was issued.  Passing barrier(k): weight tile k+1 is visible, nobody reads tile k-1 any more (its slot takes tile k+2).
+#define TD_TAPP(TAPIDX, SLOT, TOFF, TOFF_NEXT)                                                               \
+    {                                                                                                        \
+        TD_FRAG_MFMA(wfA_, xfA_);                                                                            \
+        TD_FRAG_READ(wfA_, xfA_, SLOT, 2, TOFF);                                                             \
+        TD_FRAG_MFMA(wfB_, xfB_);                                                                            \
+        TD_FRAG_READ(wfB_, xfB_, SLOT, 3, TOFF);                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);                                             \
+        TD_T(tA_);                                                                                           \
+        /* tile k+1 (issued one tap ago) has landed; only tap 0's patch loads may be younger (tap 1) */      \
+        if ((TAPIDX) == 1 && has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS) : "memory");        \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+        /* LDS returns in order: everything older than the two k-steps just requested is back */             \
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (NT + MT)) : "memory");                               \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        asm volatile("" ::: "memory");                                                                       \
+        TD_T(tB_); TD_TACC(tr_wait, tA_, tB_);                                                               \
+        if ((TAPIDX) == 3 && has_next) {                                                                     \
+            _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) asm volatile("" : "+v"(av[it_]));      \
+        }                                                                                                    \
+        TD_GLDS_B(((SLOT) + 2) % RING);                                                                      \
+        if ((TAPIDX) == 0 && has_next) TD_LOAD_A(chunk + 1);                                                 \
+        TD_FRAG_MFMA(wfA_, xfA_);                                                                            \
+        if ((TAPIDX) < 8) TD_FRAG_READ(wfA_, xfA_, ((SLOT) + 1) % RING, 0, TOFF_NEXT);                       \
+        TD_FRAG_MFMA(wfB_, xfB_);                                                                            \
+        if ((TAPIDX) < 8) TD_FRAG_READ(wfB_, xfB_, ((SLOT) + 1) % RING, 1, TOFF_NEXT);                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
+        if ((TAPIDX) < 8) __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
+        if ((TAPIDX) < 8) __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);                           \
+    }
+    // entry of a pipelined 9-tap group: this wave's patch ds_writes are out; tile k (slot 0) was issued >= 1 tap ago
+#define TD_GROUP_ENTRY()                                                                                     \
+    {                                                                                                        \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI) : "memory");                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        asm volatile("" ::: "memory");                                                                       \
+        TD_FRAG_READ(wfA_, xfA_, 0, 0, TD_TOFF(0));                                                          \
+        TD_FRAG_READ(wfB_, xfB_, 0, 1, TD_TOFF(0));                                                          \
+    }
     // 1x1 segment: one K-step per group.  The next group's patch loads go out first; the weight tile two steps ahead is fetched
     // AFTER the restage (whose compiler-inserted vmcnt(0) for the patch registers would otherwise drain a just-issued tile).
 #define TD_TAP1(SLOT, TOFF)                                                                                  \
@@ -300,7 +350,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(co
         TD_FRAG_MFMA(wfA_, xfA_);                                                                            \
         TD_FRAG_MFMA(wfB_, xfB_);                                                                            \
     }
-#define TD_TOFF(T) ((((T) / 3) * PW + ((T) % 3)) * PITCH)
     for (int seg = 0; seg < p.nseg; ++seg) {
         if (seg > 0) {  // first K-group of a later segment: its patch could not be prefetched (different source tensor / transform)
             TD_SEG_BEGIN(seg);
@@ -313,9 +362,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(co
         for (int chunk = 0; chunk < seg_nchunks; ++chunk) {
             const bool has_next = chunk + 1 < seg_nchunks;
             if (seg_taps == 9) {  // slot == 0 here: the host orders 3x3 segments before 1x1 segments, and RING divides 9
+#ifdef TD_PIPE
+                TD_GROUP_ENTRY();
+                TD_TAPP(0, 0, TD_TOFF(0), TD_TOFF(1)); TD_TAPP(1, 1, TD_TOFF(1), TD_TOFF(2)); TD_TAPP(2, 2, TD_TOFF(2), TD_TOFF(3));
+                TD_TAPP(3, 0, TD_TOFF(3), TD_TOFF(4)); TD_TAPP(4, 1, TD_TOFF(4), TD_TOFF(5)); TD_TAPP(5, 2, TD_TOFF(5), TD_TOFF(6));
+                TD_TAPP(6, 0, TD_TOFF(6), TD_TOFF(7)); TD_TAPP(7, 1, TD_TOFF(7), TD_TOFF(8)); TD_TAPP(8, 2, TD_TOFF(8), TD_TOFF(8));
+#else
                 TD_TAP(0, 0, TD_TOFF(0), false); TD_TAP(1, 1, TD_TOFF(1), true); TD_TAP(2, 2, TD_TOFF(2), true);
                 TD_TAP(3, 0, TD_TOFF(3), false); TD_TAP(4, 1, TD_TOFF(4), false); TD_TAP(5, 2, TD_TOFF(5), false);
                 TD_TAP(6, 0, TD_TOFF(6), false); TD_TAP(7, 1, TD_TOFF(7), false); TD_TAP(8, 2, TD_TOFF(8), false);
+#endif
             } else {  // centre tap only
                 if (slot == 0) TD_TAP1(0, TD_TOFF(4)) else if (slot == 1) TD_TAP1(1, TD_TOFF(4)) else TD_TAP1(2, TD_TOFF(4));
             }
@@ -338,6 +394,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(co
 #undef TD_TAP
 #undef TD_SCHED_TAP
 #undef TD_TAP1
+#undef TD_TAPP
+#undef TD_GROUP_ENTRY
 #undef TD_FRAG_READ
 #undef TD_FRAG_MFMA
 #undef TD_LOAD_A
@@ -450,7 +508,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(co
     if (lane == 0) {
         unsigned long long* tb = (unsigned long long*)p.partial + ((size_t)blockIdx.x * (WAVES_M * WAVES_N) + wave) * 8;
         tb[0] = tr_pro - tr_start; tb[1] = tr_loop - tr_pro; tb[2] = tr_end - tr_loop; tb[3] = tr_wait; tb[4] = tr_stage; tb[5] = tr_start; tb[6] = tr_end;
-        tb[7] = __builtin_amdgcn_s_getreg((3 << 11) | (4 << 6) | 4) /* HW_ID: cu/se ids, informational */;
+        tb[2] = tr_rt0; tb[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8) | __builtin_amdgcn_s_getreg((3 << 11) | 20);
+        tb[4] = __builtin_amdgcn_s_memrealtime();
+        tb[7] = tb[4] - tr_rt0;  // 100 MHz constant clock: shader clock = 100 MHz * (tb[6]-tb[5]) / tb[7]
     }
 #endif
 }

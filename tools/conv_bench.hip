@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
+#include <array>
 #include "conv_igemm.hip"
 #include "conv_glds.hip"
 using namespace td;
@@ -58,6 +59,17 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(tb.data(), partial, tb.size() * 8, hipMemcpyDeviceToHost));
         double s[5] = {0, 0, 0, 0, 0}; unsigned long long t0 = ~0ull, t1 = 0;
         for (int i = 0; i < wgs * nw; ++i) { for (int j = 0; j < 5; ++j) s[j] += (double)tb[(size_t)i * 8 + j]; if (tb[(size_t)i*8+5] && tb[(size_t)i*8+5] < t0) t0 = tb[(size_t)i*8+5]; if (tb[(size_t)i*8+6] > t1) t1 = tb[(size_t)i*8+6]; }
+        {   // per-CU timeline from the 100 MHz realtime stamps of wave 0 of every workgroup: idle gap between consecutive workgroups
+            std::vector<std::array<unsigned long long, 3>> ev;
+            for (int w = 0; w < wgs; ++w) { const unsigned long long* t = &tb[(size_t)w * nw * 8]; const unsigned long long id = t[3]; const unsigned long long cu = ((id >> 8) & 0xff00) >> 8 | (((id >> 8) >> 13) & 7) << 4 | (id & 15) << 8; ev.push_back({cu, t[2], t[4]}); }
+            std::sort(ev.begin(), ev.end());
+            double gap = 0, busy = 0; int ngap = 0, ncu = 0; unsigned long long first = ~0ull, last = 0, maxper = 0, cnt = 0;
+            for (size_t i = 0; i < ev.size(); ++i) { busy += (double)(ev[i][2] - ev[i][1]); first = std::min(first, ev[i][1]); last = std::max(last, ev[i][2]);
+                if (i == 0 || ev[i][0] != ev[i-1][0]) { ++ncu; cnt = 1; } else { gap += (double)ev[i][1] - (double)ev[i-1][2]; ++ngap; ++cnt; } maxper = std::max(maxper, cnt); }
+            printf("  timeline: %d distinct CUs, max %llu WGs on one CU, span %.1f us, mean WG %.2f us, mean idle gap between consecutive WGs on a CU %.2f us\n", ncu, maxper, (last - first) / 100.0, busy / wgs / 100.0, ngap ? gap / ngap / 100.0 : 0.0);
+        }
+        double clk = 0; for (int i = 0; i < wgs * nw; ++i) clk += 100.0 * (double)(tb[(size_t)i*8+6] - tb[(size_t)i*8+5]) / (double)tb[(size_t)i*8+7];
+        printf("  shader clock during the kernel (s_memtime / s_memrealtime): %.0f MHz\n", clk / (wgs * nw));
         for (int j = 0; j < 5; ++j) s[j] /= (double)wgs * nw;
         printf("  trace (s_memtime ticks, mean per wave): prologue %.0f  loop %.0f (of which tap-entry wait %.0f, restage %.0f, body %.0f)  epilogue %.0f  | WG total %.0f | kernel span %.0f ticks = %.2f ticks/us\n",
                s[0], s[1], s[3], s[4], s[1] - s[3] - s[4], s[2], s[0] + s[1] + s[2], (double)(t1 - t0), (double)(t1 - t0) / (ms * 1e3));
