@@ -63,7 +63,7 @@ __device__ __forceinline__ void frag_pixel(int q0, int l31, int& img, int& ty, i
 #endif
 
 template <int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4 < 2 ? 2 : (WAVES_M * WAVES_N + 3) / 4) void conv_glds_kernel(const ConvParams p) {
     typedef __bf16 T;
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
     constexpr int TPIX = TH * TW, BM = NIMG * TPIX;
@@ -231,6 +231,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(co
     TD_T(tr_pro);
 
 #define TD_TOFF(T) ((((T) / 3) * PW + ((T) % 3)) * PITCH)
+#ifdef TD_STAGGER  // the two waves of a SIMD (w, w+4) issue their LDS-DMA pieces at different points of the tap
+    const bool glds_early = (wave & 4) == 0;
+#else
+    const bool glds_early = true;
+#endif
     int slot = 0;  // ring slot of the current K-step; compile-time inside a 9-tap group (RING divides 9), tracked for 1x1 segments
     u32x4 wfA_[NT], xfA_[MT], wfB_[NT], xfB_[MT];
 #define TD_FRAG_READ(WF, XF, SLOT, KS, TOFF)                                                                 \
@@ -311,12 +316,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(co
         if ((TAPIDX) == 3 && has_next) {                                                                     \
             _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) asm volatile("" : "+v"(av[it_]));      \
         }                                                                                                    \
-        TD_GLDS_B(((SLOT) + 2) % RING);                                                                      \
+        if (glds_early) { TD_ABL_BLOAD(TD_GLDS_B(((SLOT) + 2) % RING)); }                                    \
         if ((TAPIDX) == 0 && has_next) TD_LOAD_A(chunk + 1);                                                 \
         TD_FRAG_MFMA(wfA_, xfA_);                                                                            \
         if ((TAPIDX) < 8) TD_FRAG_READ(wfA_, xfA_, ((SLOT) + 1) % RING, 0, TOFF_NEXT);                       \
         TD_FRAG_MFMA(wfB_, xfB_);                                                                            \
         if ((TAPIDX) < 8) TD_FRAG_READ(wfB_, xfB_, ((SLOT) + 1) % RING, 1, TOFF_NEXT);                       \
+        if (!glds_early) { TD_ABL_BLOAD(TD_GLDS_B(((SLOT) + 2) % RING)); }                                   \
         __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
         if ((TAPIDX) < 8) __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);                           \
         __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_glds_kernel(co
         for (int chunk = 0; chunk < seg_nchunks; ++chunk) {
             const bool has_next = chunk + 1 < seg_nchunks;
             if (seg_taps == 9) {  // slot == 0 here: the host orders 3x3 segments before 1x1 segments, and RING divides 9
-#ifdef TD_PIPE
+#ifndef TD_NO_PIPE
                 TD_GROUP_ENTRY();
                 TD_TAPP(0, 0, TD_TOFF(0), TD_TOFF(1)); TD_TAPP(1, 1, TD_TOFF(1), TD_TOFF(2)); TD_TAPP(2, 2, TD_TOFF(2), TD_TOFF(3));
                 TD_TAPP(3, 0, TD_TOFF(3), TD_TOFF(4)); TD_TAPP(4, 1, TD_TOFF(4), TD_TOFF(5)); TD_TAPP(5, 2, TD_TOFF(5), TD_TOFF(6));
@@ -540,11 +546,12 @@ static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
 //   1 "small" : 4 waves, 128-pixel tile (8x16, narrow maps 8x8 x 2 images), bn 128 -> waves 2x2 (64 px x 64 co), bn 96 -> 4x1 (32 px x 96 co);
 //               ~71 KB LDS -> two independent workgroups per CU whose prologues / epilogues / barrier stalls overlap
 hipError_t launch_conv_glds(const ConvParams& p, bool narrow, int bn, int variant, hipStream_t st) {
+    if (!narrow && bn == 192 && variant == 2) return launch_glds_cfg<16, 16, 1, 192, 4, 3>(p, st);
     if (variant == 1) {
         if (!narrow) return bn == 128 ? launch_glds_cfg<8, 16, 1, 128, 2, 2>(p, st) : launch_glds_cfg<8, 16, 1, 96, 4, 1>(p, st);
         return bn == 128 ? launch_glds_cfg<8, 8, 2, 128, 2, 2>(p, st) : launch_glds_cfg<8, 8, 2, 96, 4, 1>(p, st);
     }
-    if (!narrow && bn == 192) return launch_glds_cfg<16, 16, 1, 192, 4, 2>(p, st);
+    if (!narrow && bn == 192) return variant == 2 ? launch_glds_cfg<16, 16, 1, 192, 4, 3>(p, st) : launch_glds_cfg<16, 16, 1, 192, 4, 2>(p, st);
     if (!narrow) return bn == 128 ? launch_glds_cfg<16, 16, 1, 128, 4, 2>(p, st) : launch_glds_cfg<16, 16, 1, 96, 8, 1>(p, st);
     return bn == 128 ? launch_glds_cfg<8, 8, 4, 128, 4, 2>(p, st) : launch_glds_cfg<8, 8, 4, 96, 8, 1>(p, st);
 }
