@@ -479,7 +479,7 @@ struct SegSpec { const Tensor* t; int C; int taps; int resample; int xform; floa
 static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
     char key[64];
     snprintf(key, sizeof key, "%d_%d_%d_%d%d%d_%lld", N, H, W, (int)u->eng->option("batch_invariant", 0), (int)u->eng->option("glds", 1),
-             (int)u->eng->option("splitk", 1), (long long)u->eng->option("glds_min_wgs", 192));
+             (int)u->eng->option("splitk", 1), (long long)u->eng->option("glds_min_wgs", 96));
     auto it = u->plans.find(key);
     if (it != u->plans.end()) { *out = it->second.get(); return TD_OK; }
     if (N < 1 || N > 1023 || H > 1023 || W > 1023) return fail(TD_ERR_ARG, "batch/size out of range");
@@ -535,16 +535,26 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
         p.wpack = cw.packed->p;
         p.N = N; p.H = h; p.W = w; p.Cout = cw.cout; p.CoutPad = cw.cout_pad; p.kgroups = kgroups;
         op.narrow = w < 16;
-        // throughput flavour (bf16): 256-pixel tiles x 192/128 couts, needs enough workgroups to fill the 256 CUs
+        // throughput flavour (bf16, conv_glds.hip).  Two tile variants: "big" = 8 waves on 256 pixels (16x16, or 8x8 x 4 images),
+        // one workgroup per CU; "small" = 4 waves on 128 pixels (8x16, or 8x8 x 2 images), two workgroups per CU.  Measured on
+        // MI355X (tools/conv_bench.hip sweeps): equal when the grid is >= 4 workgroups per CU, "small" wins below that (8x8 / 16x16
+        // levels of a 64-tile batch, everything at batch <= 8), and couts go in 128s unless that leaves < 2 workgroups per CU.
+        // Every variant accumulates a given output in the same K order with the same MFMA, so they are bit-identical to each other.
         {
-            const int TH2 = op.narrow ? 8 : 16, TW2 = op.narrow ? 8 : 16, NIMG2 = op.narrow ? 4 : 1;
-            const int bn2 = cw.cout_pad % 128 == 0 ? 128 : (cw.cout_pad % 96 == 0 ? 96 : 0);
-            const int64_t mt2 = (int64_t)((w + TW2 - 1) / TW2) * ((h + TH2 - 1) / TH2) * ((N + NIMG2 - 1) / NIMG2);
+            const int TW2 = op.narrow ? 8 : 16;
+            const bool c128 = cw.cout_pad % 128 == 0, c96 = cw.cout_pad % 96 == 0;
+            auto tiles = [&](int TH, int NIMG) { return (int64_t)((w + TW2 - 1) / TW2) * ((h + TH - 1) / TH) * ((N + NIMG - 1) / NIMG); };
+            auto pick_bn = [&](int64_t mt) { return (c128 && (mt * (cw.cout_pad / 128) >= 512 || !c96)) ? 128 : (c96 ? 96 : 0); };
+            const int64_t mt_big = tiles(op.narrow ? 8 : 16, op.narrow ? 4 : 1), mt_small = tiles(8, op.narrow ? 2 : 1);
+            int variant = 0, bn2 = pick_bn(mt_big);
+            if (bn2 && mt_big * (cw.cout_pad / bn2) < 1024) { variant = 1; bn2 = pick_bn(mt_small); }
+            const int64_t mt2 = variant ? mt_small : mt_big;
             // "batch_invariant": kernel flavour and K order do not depend on the batch size (no split-K, LDS-DMA flavour whenever it
             // applies), so a window's result is bit-identical whatever other windows share its batch / GPU.
             const bool inv = u->eng->option("batch_invariant", 0) != 0;
-            if (u->bf16 && bn2 && u->eng->option("glds", 1) && (inv || mt2 * (cw.cout_pad / bn2) >= u->eng->option("glds_min_wgs", 192))) {
-                op.flavor = 2; op.bn = bn2;
+            if (u->bf16 && bn2 && u->eng->option("glds", 1) && (inv || mt2 * (cw.cout_pad / bn2) >= u->eng->option("glds_min_wgs", 96))) {
+                op.flavor = 2; op.bn = bn2; op.glds_variant = variant;
+                const int TH2 = variant ? 8 : (op.narrow ? 8 : 16), NIMG2 = op.narrow ? (variant ? 2 : 4) : 1;
                 p.tiles_x = (w + TW2 - 1) / TW2; p.tiles_y = (h + TH2 - 1) / TH2; p.img_groups = (N + NIMG2 - 1) / NIMG2;
                 p.n_ntiles = cw.cout_pad / bn2; p.ksplit = 1;
             }
@@ -742,7 +752,7 @@ static int run_unet(td_unet* u, Plan& pl, int step) {
         if (op.cvec_off >= 0) p.cvec = cbase + op.cvec_off;
         mark();
         hipError_t e = op.flavor == 2 ? launch_conv_glds(p, op.narrow, op.bn, op.glds_variant, st) : launch_conv(p, u->bf16, op.narrow, op.bn, 0, st);
-        mark(); if (prof) { ev_kind.push_back(0); char tag[96]; snprintf(tag, sizeof tag, " [%dx%d k%d f%d bn%d wg%d ks%d]", p.H, p.W, p.kgroups, op.flavor, op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit); ev_label.push_back(op.label + tag);
+        mark(); if (prof) { ev_kind.push_back(0); char tag[96]; snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 2 ? (op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit); ev_label.push_back(op.label + tag);
             double kk = 0; for (int s_ = 0; s_ < p.nseg; ++s_) kk += (double)p.seg[s_].C * p.seg[s_].taps;
             ev_flop.push_back(op.flavor == 2 ? 2.0 * p.N * p.H * p.W * (double)p.Cout * kk : 0.0); }
         if (e != hipSuccess) return fail(TD_ERR_HIP, "conv launch " + op.label + ": " + hipGetErrorString(e));

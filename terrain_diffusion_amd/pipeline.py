@@ -1,11 +1,16 @@
-"""InfiniteDiffusion latent stage on the engine: the lazy, unbounded, multi-phase counterpart of the bounded samplers.
+"""InfiniteDiffusion stages on the engine: the lazy, unbounded counterparts of the bounded samplers (coarse -> latent -> decoder).
 
 Mirrors the structure of WorldPipeline._build_latent_stage / _latent_inference (terrain_diffusion/inference/world_pipeline.py:
 1052-1131, 1133-1203): a chain of InfiniteTensors, one per trig-flow phase, windows of `tile` stride `tile//2`, every window output
 packed as (C+1, tile, tile) = (sample * w, w); a phase reads the blended (summed) previous phase through `args_windows`, divides by
 the weight channel and re-noises with the portable field seeded `seed + 5819 + phase` at absolute coordinates.  All missing
 windows of a request are batched through the U-Net (`batch_size`), noise / U-Net / consistency update run in the HIP engine.
-The conditioning source is a callback (the reference's coarse stage and synthetic-map generator are out of scope).
+The latent stage's conditioning source is a callback (the glue between the stages -- Laplacian / climate composition,
+`_process_latent_conditioning`, the synthetic-map generator -- is out of scope).
+
+build_coarse_stage / build_decoder_stage mirror `_build_coarse_stage` + `_coarse_inference` (world_pipeline.py:909-992) and
+`_build_decoder_stage` + `_decoder_inference` (world_pipeline.py:1209-1270): same window geometry, seeds, channel arithmetic and
+packing; the 20-step solver loop / trig-flow step, the noise field and the U-Net run in the HIP engine, batched over windows.
 """
 import math
 
@@ -50,3 +55,94 @@ def build_latent_stage(model, sigma_data=0.5, sigma_max=80.0, *, seed, cond_fn, 
         lat = InfiniteTensor((channels + 1, None, None), make_f(k, t), win, args=(lat,), args_windows=(win,), tile_store=store,
                              tensor_id=f"{tensor_prefix}_phase{k}", batch_size=batch_size)
     return lat
+
+
+def _pool_channel(x, n, mode):
+    """world_pipeline.py:997-1005"""
+    x = x.unsqueeze(0)
+    if mode == "max":
+        return torch.nn.functional.max_pool2d(x, kernel_size=n, stride=n).squeeze(0)
+    if mode == "min":
+        return -torch.nn.functional.max_pool2d(-x, kernel_size=n, stride=n).squeeze(0)
+    return torch.nn.functional.avg_pool2d(x, kernel_size=n, stride=n).squeeze(0)
+
+
+def pool_coarse_conditioning(img, n, elev_mode="avg", p5_mode="avg"):
+    """world_pipeline.py:1007-1015 -- (C, H*n, W*n) -> (C, H, W): channels 0 / 1 with their own pooling modes, the rest averaged."""
+    if n == 1:
+        return img
+    rest = torch.nn.functional.avg_pool2d(img[2:].unsqueeze(0), kernel_size=n, stride=n).squeeze(0)
+    return torch.cat([_pool_channel(img[0:1], n, elev_mode), _pool_channel(img[1:2], n, p5_mode), rest], dim=0)
+
+
+def build_coarse_stage(model, scheduler, *, seed, cond_map_fn, coarse_means, coarse_stds, cond_snr, coarse_pooling=1,
+                       elev_coarse_pool_mode="avg", p5_coarse_pool_mode="avg", steps=20, batch_size=16, tile_store=None,
+                       tensor_id="base_coarse_map"):
+    """InfiniteTensor (7, None, None) of packed coarse windows (world_pipeline.py:961-992).
+    model: coarse EDMUnet2D (11 -> 6 channels, five "float" conditional inputs); cond_map_fn(i1, i2, j1, j2) -> (5, 64, 64) is the
+    reference's `_conditioning_model_input` (synthetic map, channels [0,2,3,4,5] of the coarse statistics)."""
+    from .sampling import sample_tiles_edm
+    T, S = 64, 64 - 16
+    pool = int(coarse_pooling)
+    if T % pool or S % pool:
+        raise ValueError(f"coarse_pooling {pool} must divide the tile size {T} and stride {S}")
+    dev = model.device
+    means, stds = torch.as_tensor(coarse_means, dtype=torch.float32), torch.as_tensor(coarse_stds, dtype=torch.float32)
+    sel = [0, 2, 3, 4, 5]
+    sigma_data = float(scheduler.config.sigma_data)
+    w = _linear_weight_window(T // pool, dev)[0, 0].cpu()
+    t_cond = torch.atan(torch.as_tensor(cond_snr, dtype=torch.float32))                     # world_pipeline.py:976-978
+    cond_vals = torch.log(torch.tan(t_cond) / 8.0)
+    tc = t_cond.view(1, -1, 1, 1).to(dev)
+
+    def f(ctxs):
+        n = len(ctxs)
+        origins = [(c[1] * (S // pool) * pool, c[2] * (S // pool) * pool) for c in ctxs]
+        smap = torch.stack([(torch.as_tensor(cond_map_fn(i1, i1 + T, j1, j1 + T), dtype=torch.float32) - means[sel, None, None]) / stds[sel, None, None]
+                            for i1, j1 in origins]).to(dev)
+        cnoise = _noise.gaussian_noise_patches(seed, origins, T, T, channels=5, tile_h=T, tile_w=T, device=dev)
+        cond_img = (torch.cos(tc) * smap + torch.sin(tc) * cnoise).contiguous()
+        scheduler.set_timesteps(steps)
+        x = _noise.gaussian_noise_patches(seed + 1, origins, T, T, channels=6, tile_h=T, tile_w=T, device=dev) * float(scheduler.sigmas[0])
+        cond = model.cond_rows([v.view(1).expand(n) for v in cond_vals], n, dev)
+        sample_tiles_edm(model, scheduler, x, cond, steps, cond_img=cond_img)
+        x = x.cpu().float() / sigma_data                                                    # world_pipeline.py:950-952
+        x = x * stds.view(1, -1, 1, 1) + means.view(1, -1, 1, 1)
+        x[:, 1] = x[:, 0] - x[:, 1]
+        outs = []
+        for k in range(n):
+            o = pool_coarse_conditioning(x[k], pool, elev_coarse_pool_mode, p5_coarse_pool_mode)
+            outs.append(torch.cat([o * w[None], w[None]], dim=0))
+        return outs
+
+    win = TensorWindow(size=(7, T // pool, T // pool), stride=(7, S // pool, S // pool))
+    return InfiniteTensor((7, None, None), f, win, tile_store=tile_store if tile_store is not None else MemoryTileStore(), tensor_id=tensor_id,
+                          batch_size=batch_size)
+
+
+def build_decoder_stage(model, latents, *, seed, sigma_data=0.5, sigma_max=80.0, tile_size=512, tile_stride=384, latent_compression=8,
+                        extra_ts=(), batch_size=4, tile_store=None, tensor_id="init_residual_map"):
+    """InfiniteTensor (2, None, None) of packed decoder windows (world_pipeline.py:1244-1270) over the latent stage's tensor `latents`
+    ((6, None, None): 5 latent channels + weight).  One trig-flow step at t = atan(sigma_max / sigma_data) (+ `extra_ts`)."""
+    from .sampling import consistency_step
+    T, S, lc = int(tile_size), int(tile_stride), int(latent_compression)
+    dev = model.device
+    w = _linear_weight_window(T, dev)[0, 0].cpu()
+    t_list = (float(torch.atan(torch.tensor(sigma_max, dtype=torch.float32) / sigma_data)),) + tuple(float(torch.as_tensor(t, dtype=torch.float32)) for t in extra_ts)
+
+    def f(ctxs, lats):
+        n = len(ctxs)
+        origins = [(c[1] * S, c[2] * S) for c in ctxs]
+        lat = torch.stack([(torch.as_tensor(p)[:-1] / torch.as_tensor(p)[-1:])[:4] for p in lats]).to(dev, dtype=torch.float32)   # :1223
+        up = lat.repeat_interleave(T // lat.shape[-2], dim=-2).repeat_interleave(T // lat.shape[-1], dim=-1).contiguous()         # nearest, :1224
+        sample = None
+        for i, t in enumerate(t_list):
+            z = _noise.gaussian_noise_patches(seed + 5819 + i, origins, T, T, channels=1, tile_h=T, tile_w=T, device=dev)
+            sample = consistency_step(model, t, sigma_data, sample, z, cond=None, cond_img=up)
+        out = sample.cpu().float() / sigma_data
+        return [torch.cat([o * w[None], w[None]], dim=0) for o in out]
+
+    owin = TensorWindow(size=(2, T, T), stride=(2, S, S))
+    iwin = TensorWindow(size=(6, T // lc, T // lc), stride=(6, S // lc, S // lc))
+    return InfiniteTensor((2, None, None), f, owin, args=(latents,), args_windows=(iwin,),
+                          tile_store=tile_store if tile_store is not None else MemoryTileStore(), tensor_id=tensor_id, batch_size=batch_size)

@@ -328,7 +328,62 @@ def gen_stages():
     save("stages", **out)
 
 
-ALL = dict(stages=gen_stages, rng=gen_rng, geometry=gen_geometry, schedule=gen_schedule, unet=gen_unet, sampling=gen_sampling)
+def extract_methods(path, cls, names, namespace):
+    """exec the named methods of class `cls` of a reference file as plain functions (first argument = self)."""
+    tree = ast.parse(open(path).read())
+    body = [m for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls for m in n.body if isinstance(m, ast.FunctionDef) and m.name in names]
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), namespace)
+    return namespace
+
+
+def gen_stage_glue():
+    """Per-window glue of the coarse and decoder stages: the reference's own WorldPipeline._coarse_inference /
+    _pool_coarse_conditioning / _decoder_inference bodies (world_pipeline.py:909-959, 997-1015, 1209-1242) run against a stub `self`
+    carrying reference EDMUnet2D models with the synthetic weights (coarse: the full-size coarse config; decoder: the full-size
+    decoder config on a 64-pixel tile, stride 48) and the deterministic synthetic map of oracle/stages.py."""
+    from terrain_diffusion.inference import portable_rng as pr
+    from terrain_diffusion.scheduler.dpmsolver import EDMDPMSolverMultistepScheduler
+    from oracle.unet import COARSE_CONFIG, DECODER_CONFIG, synth_state_dict
+    from oracle import stages
+    wp = os.path.join(REF, "terrain_diffusion/inference/world_pipeline.py")
+    ns = extract_functions(wp, {"_tile_seed", "gaussian_noise_patch", "linear_weight_window"},
+                           {"np": np, "torch": torch, "fill_standard_normal": pr.fill_standard_normal, "MOCK": False})
+    extract_methods(wp, "WorldPipeline", {"_coarse_inference", "_pool_channel", "_pool_coarse_conditioning", "_decoder_inference"}, ns)
+    means = [0.3, -0.2, 0.1, 0.0, 0.4, -0.1]; stds = [1.5, 0.8, 1.2, 0.9, 1.1, 0.7]; snr = [0.5, 0.4, 0.6, 0.3, 0.8]
+    mc = _ref_model(dict(COARSE_CONFIG), synth_state_dict(COARSE_CONFIG, seed=4321))
+    md = _ref_model(dict(DECODER_CONFIG), synth_state_dict(DECODER_CONFIG, seed=2468))
+    self = types.SimpleNamespace(kwargs=dict(coarse_means=means, coarse_stds=stds, elev_coarse_pool_mode="max", p5_coarse_pool_mode="min"),
+                                 _dtype=None, device="cpu", seed=1234, log_mode="quiet", coarse_model=mc, decoder_model=md, latent_compression=8,
+                                 _conditioning_model_input=stages.synthetic_coarse_map)
+    self._pool_channel = lambda *a: ns["_pool_channel"](self, *a)
+    self._pool_coarse_conditioning = lambda *a: ns["_pool_coarse_conditioning"](self, *a)
+    out = {"coarse_means": np.array(means, np.float32), "coarse_stds": np.array(stds, np.float32), "cond_snr": np.array(snr, np.float32)}
+    sched = EDMDPMSolverMultistepScheduler(sigma_min=0.002, sigma_max=80, sigma_data=0.5)
+    t_cond = torch.atan(torch.tensor(snr))
+    cond_inputs = [v.detach().view(-1) for v in torch.log(torch.tan(t_cond) / 8.0)]
+    with torch.no_grad():
+        for name, ctx, pool in [("coarse_ctx_0_1_m2_pool1", (0, 1, -2), 1), ("coarse_ctx_0_m1_0_pool2", (0, -1, 0), 2)]:
+            w = ns["linear_weight_window"](64 // pool, "cpu", torch.float32)
+            out[name] = ns["_coarse_inference"](self, ctx, sched, w, t_cond, cond_inputs, pool_size=pool).numpy()
+        pin = torch.from_numpy(pr.standard_normal(77, (6, 16, 16)))
+        out["pool_in"] = pin.numpy()
+        out["pool4_max_min"] = ns["_pool_coarse_conditioning"](self, pin, 4).numpy()
+        # decoder: tile 64, stride 48, latent window (6, 8, 8) = packed un-normalised sums (weight channel last)
+        T, S = 64, 48
+        lat = torch.from_numpy(pr.standard_normal(78, (6, T // 8, T // 8)))
+        lat[-1] = lat[-1].abs() + 0.5
+        out["decoder_latents_in"] = lat.numpy()
+        t_list = [torch.atan(sched.sigmas[0] / sched.config.sigma_data)] if hasattr(sched, "sigmas") else None
+        sched.set_timesteps(20)
+        t_list = [torch.atan(sched.sigmas[0] / sched.config.sigma_data)]
+        wd = ns["linear_weight_window"](T, "cpu", torch.float32)
+        out["decoder_ctx_0_2_m1"] = ns["_decoder_inference"](self, (0, 2, -1), lat.clone(), sched, wd, t_list, T, S).numpy()
+        t2 = t_list + [torch.arctan(torch.tensor(0.065) / 0.5)]   # the commented-out second phase of wp.py:1253: exercises i > 0
+        out["decoder_ctx_0_2_m1_two_phases"] = ns["_decoder_inference"](self, (0, 2, -1), lat.clone(), sched, wd, t2, T, S).numpy()
+    save("stage_glue", **out)
+
+
+ALL = dict(stage_glue=gen_stage_glue, stages=gen_stages, rng=gen_rng, geometry=gen_geometry, schedule=gen_schedule, unet=gen_unet, sampling=gen_sampling)
 
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden generation needs the reference checkout"

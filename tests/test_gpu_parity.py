@@ -487,3 +487,47 @@ def test_coarse_stage_loop_and_decoder_step_vs_oracle(td, orc):
         ref = torch.cos(tt) * x_t - torch.sin(tt) * 0.5 * pred
     assert rel_rms(out.cpu().numpy(), ref.numpy()) < 1e-5
     md.close()
+
+
+def test_coarse_and_decoder_stage_builders_vs_reference_golden(td, orc, golden):
+    """build_coarse_stage / build_decoder_stage (engine, fp32 mode) reproduce the windows that the reference's own _coarse_inference /
+    _decoder_inference produced (tests/golden/stage_glue.npz), window by window and as the blended InfiniteTensor region."""
+    from oracle.unet import COARSE_CONFIG, DECODER_CONFIG
+    from oracle import stages
+    from terrain_diffusion_amd.pipeline import build_coarse_stage, build_decoder_stage, pool_coarse_conditioning
+    from terrain_diffusion_amd.infinite_tensor import InfiniteTensor, TensorWindow
+    U = orc["unet"]
+    g = golden("stage_glue")
+    assert np.array_equal(pool_coarse_conditioning(torch.from_numpy(g["pool_in"]), 4, "max", "min").numpy(), g["pool4_max_min"])
+    mc = td.EDMUnet2D(**COARSE_CONFIG, dtype="fp32").load_state_dict(U.synth_state_dict(COARSE_CONFIG, seed=4321))
+    sch = td.EDMDPMSolverMultistepScheduler()
+    for name, ctx, pool in [("coarse_ctx_0_1_m2_pool1", (0, 1, -2), 1), ("coarse_ctx_0_m1_0_pool2", (0, -1, 0), 2)]:
+        cs = build_coarse_stage(mc, sch, seed=1234, cond_map_fn=stages.synthetic_coarse_map, coarse_means=g["coarse_means"], coarse_stds=g["coarse_stds"],
+                                cond_snr=g["cond_snr"], coarse_pooling=pool, elev_coarse_pool_mode="max", p5_coarse_pool_mode="min")
+        win = cs.f([ctx])[0]
+        assert win.shape == (7, 64 // pool, 64 // pool) and np.array_equal(win[-1].numpy(), g[name][-1])
+        assert rel_rms(win.numpy(), g[name]) < 1e-5, name
+    # blended region == sum of the overlapping windows (stride 48 on tile 64): rows 48..63 x cols 16..95 are covered by windows
+    # i, j in {0, 1} only (window k spans [48k, 48k + 64))
+    cs = build_coarse_stage(mc, sch, seed=1234, cond_map_fn=stages.synthetic_coarse_map, coarse_means=g["coarse_means"], coarse_stds=g["coarse_stds"],
+                            cond_snr=g["cond_snr"], batch_size=4)
+    region = torch.as_tensor(cs[:, 48:64, 16:96])
+    wins = {(i, j): cs.f([(0, i, j)])[0] for i in (0, 1) for j in (0, 1)}
+    ref = torch.zeros(7, 16, 80)
+    for (i, j), wv in wins.items():
+        ys = slice(48 - 48 * i, 64 - 48 * i)
+        xs0, xs1 = max(16, 48 * j), min(96, 48 * j + 64)
+        ref[:, :, xs0 - 16:xs1 - 16] += wv[:, ys, xs0 - 48 * j:xs1 - 48 * j]
+    assert torch.allclose(region, ref, rtol=1e-5, atol=1e-5)
+    mc.close()
+    # ---- decoder (tile 64, stride 48, latent compression 8): feed the golden latent window through an InfiniteTensor source
+    md = td.EDMUnet2D(**DECODER_CONFIG, dtype="fp32").load_state_dict(U.synth_state_dict(DECODER_CONFIG, seed=2468))
+    lat_win = torch.from_numpy(g["decoder_latents_in"])
+    src = InfiniteTensor((6, None, None), lambda ctx: lat_win, TensorWindow(size=(6, 8, 8), stride=(6, 8, 8)), tensor_id="lat_src")
+    ds = build_decoder_stage(md, src, seed=1234, tile_size=64, tile_stride=48)
+    out = ds.f([(0, 2, -1)], [lat_win])[0]
+    assert out.shape == (2, 64, 64) and rel_rms(out.numpy(), g["decoder_ctx_0_2_m1"]) < 1e-5
+    ds2 = build_decoder_stage(md, src, seed=1234, tile_size=64, tile_stride=48, extra_ts=(float(torch.arctan(torch.tensor(0.065) / 0.5)),))
+    out2 = ds2.f([(0, 2, -1)], [lat_win])[0]
+    assert rel_rms(out2.numpy(), g["decoder_ctx_0_2_m1_two_phases"]) < 1e-5
+    md.close()

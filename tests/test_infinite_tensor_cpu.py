@@ -152,3 +152,16 @@ def test_config0_panorama_plumbing_two_tiles_four_steps():
         acc[:, :, a:e] += phase_value(2, k, memo)[:, :, a - k * S:e - k * S]
     assert torch.equal(region, pano.normalize(acc))
     assert region.shape == (C, T, 96) and torch.isfinite(region).all()
+
+
+def test_pool_coarse_conditioning_host_matches_reference_golden(golden):
+    """host glue of the coarse stage (world_pipeline.py:997-1015) against the reference's output"""
+    import numpy as np
+    import torch
+    from terrain_diffusion_amd.pipeline import pool_coarse_conditioning
+    g = golden("stage_glue")
+    x = torch.from_numpy(g["pool_in"])
+    assert np.array_equal(pool_coarse_conditioning(x, 4, "max", "min").numpy(), g["pool4_max_min"])
+    assert pool_coarse_conditioning(x, 1) is x
+    avg = pool_coarse_conditioning(x, 2)
+    assert avg.shape == (6, 8, 8) and torch.allclose(avg[0], x[0].view(8, 2, 8, 2).mean(dim=(1, 3)))

@@ -221,3 +221,30 @@ def test_coarse_and_decoder_models_vs_reference(golden):
     xd = torch.from_numpy(rng.standard_normal(43, (1, 5, 64, 64)))
     with torch.no_grad():
         assert rel_rms(md(xd, torch.tensor([1.5]), []).numpy(), g["decoder_out"]) < 5e-6
+
+
+# ------------------------------------------------------------------------------------------- stage glue (coarse / decoder windows)
+def test_stage_glue_oracle_matches_reference(golden):
+    """oracle/stages.py against the outputs of the reference's own _coarse_inference / _pool_coarse_conditioning /
+    _decoder_inference bodies (tests/golden/make_golden.py::gen_stage_glue)."""
+    import torch
+    from oracle import stages
+    from oracle.unet import COARSE_CONFIG, DECODER_CONFIG, OracleUnet, synth_state_dict
+    g = golden("stage_glue")
+    means, stds, snr = g["coarse_means"], g["coarse_stds"], g["cond_snr"]
+    pooled = stages.pool_coarse_conditioning(torch.from_numpy(g["pool_in"]), 4, "max", "min").numpy()
+    assert np.array_equal(pooled, g["pool4_max_min"])
+    mc = OracleUnet(COARSE_CONFIG, synth_state_dict(COARSE_CONFIG, seed=4321))
+    for name, ctx, pool in [("coarse_ctx_0_1_m2_pool1", (0, 1, -2), 1), ("coarse_ctx_0_m1_0_pool2", (0, -1, 0), 2)]:
+        out = stages.coarse_inference(mc, ctx, seed=1234, cond_map_fn=stages.synthetic_coarse_map, means=means, stds=stds, cond_snr=snr,
+                                      pool_size=pool, elev_mode="max", p5_mode="min").numpy()
+        assert out.shape == g[name].shape == (7, 64 // pool, 64 // pool)
+        assert np.array_equal(out[-1], g[name][-1])                       # weight channel: exact
+        assert rel_rms(out, g[name]) < 5e-6, name
+    md = OracleUnet(DECODER_CONFIG, synth_state_dict(DECODER_CONFIG, seed=2468))
+    lat = torch.from_numpy(g["decoder_latents_in"])
+    out = stages.decoder_inference(md, (0, 2, -1), lat, seed=1234, tile_size=64, tile_stride=48).numpy()
+    assert rel_rms(out, g["decoder_ctx_0_2_m1"]) < 5e-6
+    t0 = torch.atan(torch.tensor(80.0) / 0.5)
+    out2 = stages.decoder_inference(md, (0, 2, -1), lat, seed=1234, tile_size=64, tile_stride=48, t_list=[t0, torch.arctan(torch.tensor(0.065) / 0.5)]).numpy()
+    assert rel_rms(out2, g["decoder_ctx_0_2_m1_two_phases"]) < 5e-6

@@ -1,0 +1,53 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (gpurun): rocprofv3 kernel statistics + separate PMC passes of the default bench command, condensed into
+# gpurun_out/profiles_new/ (copy what should be judged into profiles/).  PMC passes carry counters only (no API traces).
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/profiles_new; rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
+for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
+  tag=$(echo $c | cut -d' ' -f1)
+  timeout 900 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$tag -- $BENCH > $OUT/pmc_$tag.log 2>&1
+done
+python3 - <<'PY'
+import csv, glob, os, json, collections
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); out = R + "/gpurun_out/profiles_new"
+# kernel stats
+for f in glob.glob(out + "/kt/**/*kernel_stats.csv", recursive=True): os.replace(f, out + "/kernel_stats.csv")
+agg = collections.defaultdict(lambda: [0, 0.0])
+for f in glob.glob(out + "/kt/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        a = agg[r["Kernel_Name"].split("(")[0]]; a[0] += 1; a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+tot = sum(v[1] for v in agg.values()) or 1.0
+with open(out + "/kernel_trace_summary.csv", "w") as o:
+    o.write("kernel,calls,total_us,avg_us,percent\n")
+    for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]): o.write(f"\"{k}\",{n},{t:.1f},{t/n:.2f},{100*t/tot:.2f}\n")
+# counters
+cnt = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        a = cnt[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+with open(out + "/pmc_counters_summary.csv", "w") as o:
+    o.write("kernel,counter,dispatches,avg_per_dispatch\n")
+    for k, cs in sorted(cnt.items()):
+        for c, (n, v) in sorted(cs.items()): o.write(f"\"{k}\",{c},{n},{v/n:.1f}\n")
+kern = {}
+for k, cs in cnt.items():
+    if "conv" not in k: continue
+    g = lambda c: (cs[c][1] / cs[c][0]) if c in cs and cs[c][0] else None
+    e = {"dispatches": cs["FETCH_SIZE"][0] if "FETCH_SIZE" in cs else 0}
+    if g("FETCH_SIZE") is not None: e["hbm_read_bytes_per_launch"] = round(g("FETCH_SIZE") * 1024 * 2)   # KB; doubled: gfx950 correction (guide)
+    if g("WRITE_SIZE") is not None: e["hbm_write_bytes_per_launch"] = round(g("WRITE_SIZE") * 1024)
+    if g("SQ_VALU_MFMA_BUSY_CYCLES") and g("GRBM_GUI_ACTIVE"): e["mfma_util"] = round(g("SQ_VALU_MFMA_BUSY_CYCLES") / (g("GRBM_GUI_ACTIVE") / 8 * 1024), 4)  # busy cycles / (cycles per XCD x 256 CUs x 4 SIMDs)
+    if g("SQ_LDS_IDX_ACTIVE"): e["lds_bank_conflict_share"] = round((g("SQ_LDS_BANK_CONFLICT") or 0.0) / g("SQ_LDS_IDX_ACTIVE"), 4)
+    if g("SQ_WAVE_CYCLES"): e.update({"wait_any_share": round(g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 4), "wait_inst_share": round(g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"), 4), "active_inst_share": round(g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES"), 4)})
+    if g("SQ_INSTS_VALU") and g("SQ_INSTS_VALU_MFMA_MOPS_BF16"):
+        mfma = g("SQ_INSTS_VALU_MFMA_MOPS_BF16") / 64.0   # MOPS counter: 64 per 32x32x16 bf16 MFMA (32768 flop / 512)
+        e["valu_per_mfma"] = round((g("SQ_INSTS_VALU") - mfma) / mfma, 2) if mfma else None
+    kern[k] = e
+json.dump({"note": "rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile` (batch 64 x 20 solver steps per bench step). FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced stream); WRITE_SIZE uncalibrated; units KB -> bytes x1024. mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs).", "kernels": kern}, open(out + "/hbm_traffic_and_mfma_util.json", "w"), indent=1)
+print(open(out + "/kernel_trace_summary.csv").read()[:1500])
+PY
+rm -rf $OUT/kt $OUT/pmc_*/  # raw traces are large; the summaries are what gets committed
+ls -la $OUT
