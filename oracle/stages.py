@@ -93,3 +93,49 @@ def synthetic_coarse_map(i1, i2, j1, j2):
     y = torch.arange(i1, i2, dtype=torch.float32)[:, None]
     x = torch.arange(j1, j2, dtype=torch.float32)[None, :]
     return torch.stack([torch.sin(0.05 * y + 0.3 * k) * torch.cos(0.03 * x - 0.2 * k) * (1.0 + 0.5 * k) + 0.1 * k for k in range(5)])
+
+
+def process_latent_conditioning(cond_img, histogram_raw, cond_means, cond_stds, noise_level, *, seed, seed_offset=0):
+    """wp.py:1018-1050, literally.  NOTE the reference indexes the BATCH dimension when it fills NaNs (`cond_img[0:1]`, `cond_img[1:2]`):
+    every NaN of sample 0 (all channels, after normalisation) becomes cond_means[0], of sample 1 cond_means[1]; further samples keep
+    their NaNs and the NaN climate means are then drawn from the portable RNG seeded seed + 9999 + seed_offset.  (B,7,4,4) -> (B,58)."""
+    cond_means = torch.as_tensor(cond_means, dtype=torch.float32)
+    cond_stds = torch.as_tensor(cond_stds, dtype=torch.float32)
+    cond_img = (cond_img.to(torch.float32) - cond_means.view(1, -1, 1, 1)) / cond_stds.view(1, -1, 1, 1)
+    cond_img[0:1] = cond_img[0:1].nan_to_num(float(cond_means[0]))
+    cond_img[1:2] = cond_img[1:2].nan_to_num(float(cond_means[1]))
+    clim = cond_img[:, 2:6, 1:3, 1:3].mean(dim=(2, 3))
+    nan_mask = torch.isnan(clim)
+    cnt = int(nan_mask.sum())
+    if cnt > 0:
+        clim[nan_mask] = torch.from_numpy(rng.standard_normal((seed + 9999 + seed_offset), (cnt,)))
+    nl = (torch.as_tensor(noise_level, dtype=torch.float32) - 0.5) * np.sqrt(12)
+    parts = [cond_img[:, 0:1].flatten(1), cond_img[:, 1:2].flatten(1), clim.flatten(1), cond_img[:, 6:7].flatten(1),
+             torch.as_tensor(histogram_raw, dtype=torch.float32), nl.view(-1, 1)]
+    return tiling.mp_concat_list(parts, dim=1).float()
+
+
+def latent_inference(model, ctxs, samples, cond_windows, t, *, seed, seed_offset, histogram_raw, cond_means, cond_stds):
+    """wp.py:1052-1131.  samples: None or packed (6,64,64) previous-phase sums; cond_windows: packed (7,4,4) coarse windows.
+    Returns the packed (6,64,64) windows."""
+    T, S = 64, 32
+    w = tiling.linear_weight_window(T)
+    t = torch.as_tensor(t, dtype=torch.float32)
+    tv = t.view(1, 1, 1, 1)
+    outs = []
+    with torch.no_grad():
+        for k, ctx in enumerate(ctxs):
+            if samples is None or samples[k] is None:
+                sample = torch.zeros(1, 5, T, T)
+            else:
+                s_ = torch.as_tensor(samples[k], dtype=torch.float32)
+                sample = (s_[:-1] / s_[-1:] * SIGMA_DATA)[None]
+            c = torch.as_tensor(cond_windows[k], dtype=torch.float32)
+            cimg = torch.cat([c[:-1] / c[-1:], torch.ones(1, 4, 4)], dim=0)[None]
+            cond = process_latent_conditioning(cimg, histogram_raw, cond_means, cond_stds, torch.tensor(0.0), seed=seed, seed_offset=ctx[1] * 65536 + ctx[2])
+            z = torch.from_numpy(rng.gaussian_noise_patch(seed + seed_offset, ctx[1] * S, ctx[2] * S, T, T, 5, T, T))[None] * SIGMA_DATA
+            x_t = torch.cos(tv) * sample + torch.sin(tv) * z
+            pred = -model(x_t / SIGMA_DATA, t.view(1), [cond])
+            out = (torch.cos(tv) * x_t - torch.sin(tv) * SIGMA_DATA * pred) / SIGMA_DATA
+            outs.append(torch.cat([out[0] * w[None], w[None]], dim=0))
+    return outs

@@ -23,37 +23,76 @@ from . import noise as _noise
 from .sampling import _linear_weight_window
 
 
-def build_latent_stage(model, sigma_data=0.5, sigma_max=80.0, *, seed, cond_fn, intermediate_ts=(math.atan(0.35 / 0.5),), tile=64, channels=5,
-                       batch_size=16, tile_store=None, tensor_prefix="latents"):
-    """Returns the final-phase InfiniteTensor of shape (channels+1, None, None).
-    cond_fn(ctxs) -> (len(ctxs), cond_dim) conditioning vectors for window indices ctxs = [(0, i, j), ...]."""
+LATENT_COND_MEAN = (14.99, 11.65, 15.87, 619.26, 833.12, 69.40, 0.66)     # world_pipeline.py:1137-1138
+LATENT_COND_STD = (21.72, 21.78, 10.40, 452.29, 738.09, 34.59, 0.47)
+
+
+def build_latent_stage(model, sigma_data=0.5, sigma_max=80.0, *, seed, cond_fn=None, coarse=None, histogram_raw=None,
+                       cond_means=LATENT_COND_MEAN, cond_stds=LATENT_COND_STD, intermediate_ts=(math.atan(0.35 / 0.5),), T=2,
+                       onestep_latent=False, tile=64, channels=5, batch_size=16, tile_store=None, tensor_prefix="latents"):
+    """Returns the final-phase InfiniteTensor of shape (channels+1, None, None)  (world_pipeline.py:1133-1203).
+
+    Conditioning source, one of
+      coarse=<InfiniteTensor (7,None,None)> (+ histogram_raw): the reference's wiring -- each latent window reads the (7,4,4) coarse
+        window at the same index through TensorWindow(size=(7,4,4), stride=(7,1,1), offset=(0,-1,-1)), normalises it, appends the
+        ones mask and goes through process_latent_conditioning with seed_offset = i*65536 + j (world_pipeline.py:1080-1088);
+      cond_fn(ctxs) -> (len(ctxs), cond_dim): a caller-supplied conditioning matrix for window indices ctxs = [(0, i, j), ...].
+    T=2: one InfiniteTensor per trig-flow phase, blended between phases; T=1: all phases inside one window function
+    (world_pipeline.py:1149-1172).  onestep_latent stops after the first phase."""
+    from .sampling import process_latent_conditioning
+    if (cond_fn is None) == (coarse is None):
+        raise ValueError("give exactly one of cond_fn= or coarse=")
     stride = tile // 2
     store = tile_store if tile_store is not None else MemoryTileStore()
     dev = model.device
     w = _linear_weight_window(tile, dev)[0, 0].cpu()
     win = TensorWindow(size=(channels + 1, tile, tile), stride=(channels + 1, stride, stride))
+    cwin = TensorWindow(size=(7, 4, 4), stride=(7, 1, 1), offset=(0, -1, -1))
     t_init = float(torch.atan(torch.tensor(sigma_max, dtype=torch.float32) / sigma_data))
-    ts = (t_init,) + tuple(float(torch.tensor(t, dtype=torch.float32)) for t in intermediate_ts)
+    ts = (t_init,) + (() if onestep_latent else tuple(float(torch.as_tensor(t, dtype=torch.float32)) for t in intermediate_ts))
+    hist = None if histogram_raw is None else torch.as_tensor(histogram_raw, dtype=torch.float32).view(1, -1)
 
-    def make_f(phase, t):
-        def f(ctxs, prevs=None):
-            n = len(ctxs)
-            origins = [(c[1] * stride, c[2] * stride) for c in ctxs]
-            z = _noise.gaussian_noise_patches(seed + 5819 + phase, origins, tile, tile, channels=channels, tile_h=tile, tile_w=tile, device=dev)
-            sample = None
-            if prevs is not None:  # (C+1, tile, tile) un-normalised sums -> sample * sigma_data (world_pipeline.py:1078)
-                sample = torch.stack([(p[:-1] / p[-1:]) * sigma_data for p in prevs]).to(dev).contiguous()
-            cond = torch.as_tensor(cond_fn(ctxs), dtype=torch.float32).to(dev).contiguous()
-            out = torch.empty_like(z)
-            check(lib().td_sample_consistency(model._h, n, tile, tile, float(t), float(sigma_data), ptr(sample), ptr(z), ptr(cond), ptr(out)))
-            out = out.cpu() / sigma_data  # world_pipeline.py:1129
-            return [torch.cat([o * w[None], w[None]], dim=0) for o in out]
-        return f
+    def conditioning(ctxs, conds):
+        if coarse is None:
+            return torch.as_tensor(cond_fn(ctxs), dtype=torch.float32)
+        rows = []
+        for ctx, c in zip(ctxs, conds):
+            c = torch.as_tensor(c, dtype=torch.float32)
+            cimg = torch.cat([c[:-1] / c[-1:], torch.ones(1, 4, 4)], dim=0)[None]                     # world_pipeline.py:1080-1083
+            rows.append(process_latent_conditioning(cimg, hist, cond_means, cond_stds, 0.0, seed=seed, seed_offset=ctx[1] * 65536 + ctx[2]))
+        return torch.cat(rows, dim=0)
 
-    lat = InfiniteTensor((channels + 1, None, None), make_f(0, ts[0]), win, tile_store=store, tensor_id=f"{tensor_prefix}_phase0", batch_size=batch_size)
+    def infer(phase, t, ctxs, prevs, conds):
+        n = len(ctxs)
+        origins = [(c[1] * stride, c[2] * stride) for c in ctxs]
+        z = _noise.gaussian_noise_patches(seed + 5819 + phase, origins, tile, tile, channels=channels, tile_h=tile, tile_w=tile, device=dev)
+        sample = None
+        if prevs is not None:  # (C+1, tile, tile) un-normalised sums -> sample * sigma_data (world_pipeline.py:1078)
+            sample = torch.stack([(torch.as_tensor(p)[:-1] / torch.as_tensor(p)[-1:]) * sigma_data for p in prevs]).to(dev, dtype=torch.float32).contiguous()
+        cond = conditioning(ctxs, conds).to(dev).contiguous()
+        out = torch.empty_like(z)
+        check(lib().td_sample_consistency(model._h, n, tile, tile, float(t), float(sigma_data), ptr(sample), ptr(z), ptr(cond), ptr(out)))
+        out = out.cpu() / sigma_data  # world_pipeline.py:1129
+        return [torch.cat([o * w[None], w[None]], dim=0) for o in out]
+
+    src_args, src_wins = ((coarse,), (cwin,)) if coarse is not None else ((), ())
+    shape = (channels + 1, None, None)
+    if T == 1:
+        def f_t1(ctxs, conds=None):
+            outs = None
+            for k, t in enumerate(ts):
+                outs = infer(k, t, ctxs, outs, conds)
+            return outs
+        lat = InfiniteTensor(shape, f_t1, win, args=src_args, args_windows=src_wins, tile_store=store, tensor_id=f"{tensor_prefix}_T1",
+                             batch_size=batch_size)
+        lat.infer = infer
+        return lat
+    lat = InfiniteTensor(shape, lambda ctxs, conds=None: infer(0, ts[0], ctxs, None, conds), win, args=src_args, args_windows=src_wins,
+                         tile_store=store, tensor_id=f"{tensor_prefix}_phase0", batch_size=batch_size)
     for k, t in enumerate(ts[1:], 1):
-        lat = InfiniteTensor((channels + 1, None, None), make_f(k, t), win, args=(lat,), args_windows=(win,), tile_store=store,
-                             tensor_id=f"{tensor_prefix}_phase{k}", batch_size=batch_size)
+        lat = InfiniteTensor(shape, lambda ctxs, prevs, conds=None, k=k, t=t: infer(k, t, ctxs, prevs, conds), win, args=(lat,) + src_args,
+                             args_windows=(win,) + src_wins, tile_store=store, tensor_id=f"{tensor_prefix}_phase{k}", batch_size=batch_size)
+    lat.infer = infer   # the per-window arithmetic, exposed for parity tests
     return lat
 
 

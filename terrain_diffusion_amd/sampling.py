@@ -52,6 +52,32 @@ def _process_cond_img(cond_img, histogram_raw, cond_means, cond_stds, noise_leve
     return torch.cat([p * (Cc / math.sqrt(p.shape[1]) * (1.0 / n)) for p in parts], dim=1).float()
 
 
+def process_latent_conditioning(cond_img, histogram_raw, cond_means, cond_stds, noise_level=0.0, *, seed, seed_offset=0):
+    """WorldPipeline._process_latent_conditioning (world_pipeline.py:1018-1050) on the host: (B,7,4,4) -> (B,58).
+    Keeps the reference's behaviour to the letter, including its batch-dimension NaN fill: every NaN of sample 0 becomes cond_means[0]
+    and of sample 1 cond_means[1] (after normalisation); NaN climate means of further samples are drawn from the portable RNG seeded
+    seed + 9999 + seed_offset (the engine's generator: same stream as portable_rng.standard_normal)."""
+    from .noise import standard_normal
+    cond_means = torch.as_tensor(cond_means, dtype=torch.float32)
+    cond_stds = torch.as_tensor(cond_stds, dtype=torch.float32)
+    cond_img = (torch.as_tensor(cond_img, dtype=torch.float32).cpu() - cond_means.view(1, -1, 1, 1)) / cond_stds.view(1, -1, 1, 1)
+    cond_img[0:1] = cond_img[0:1].nan_to_num(float(cond_means[0]))
+    cond_img[1:2] = cond_img[1:2].nan_to_num(float(cond_means[1]))
+    clim = cond_img[:, 2:6, 1:3, 1:3].mean(dim=(2, 3))
+    nan_mask = torch.isnan(clim)
+    cnt = int(nan_mask.sum())
+    if cnt > 0:
+        clim[nan_mask] = torch.from_numpy(standard_normal(seed + 9999 + seed_offset, (cnt,), dtype=np.float32))
+    B = cond_img.shape[0]
+    nl = (torch.as_tensor(noise_level, dtype=torch.float32) - 0.5) * np.sqrt(12)
+    hist = torch.as_tensor(histogram_raw, dtype=torch.float32)
+    parts = [cond_img[:, 0:1].flatten(1), cond_img[:, 1:2].flatten(1), clim.flatten(1), cond_img[:, 6:7].flatten(1),
+             hist.view(-1, hist.shape[-1]).expand(B, -1), nl.view(-1, 1).expand(B, 1)]
+    n = len(parts)
+    Cc = math.sqrt(sum(p.shape[1] for p in parts) / (n * (1.0 / n) ** 2))
+    return torch.cat([p * (Cc / math.sqrt(p.shape[1]) * (1.0 / n)) for p in parts], dim=1).float()
+
+
 def _tile_conditioning(cond_inputs, tiles, histogram_raw, cond_means, cond_stds, noise_level):
     if cond_inputs.ndim == 4:
         return torch.cat([_process_cond_img(cond_inputs[..., ic:ic + 4, jc:jc + 4], histogram_raw, cond_means, cond_stds, noise_level)

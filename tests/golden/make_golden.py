@@ -383,7 +383,57 @@ def gen_stage_glue():
     save("stage_glue", **out)
 
 
-ALL = dict(stage_glue=gen_stage_glue, stages=gen_stages, rng=gen_rng, geometry=gen_geometry, schedule=gen_schedule, unet=gen_unet, sampling=gen_sampling)
+def gen_latent_glue():
+    """WorldPipeline._process_latent_conditioning (incl. its NaN handling and portable-RNG fill) and _latent_inference
+    (world_pipeline.py:1018-1131) run from the reference's own method bodies against a stub `self` with a tiny reference base model."""
+    from terrain_diffusion.inference import portable_rng as pr
+    from terrain_diffusion.models.mp_layers import mp_concat
+    from terrain_diffusion.scheduler.dpmsolver import EDMDPMSolverMultistepScheduler
+    from oracle.unet import tiny_config, synth_state_dict
+    wp = os.path.join(REF, "terrain_diffusion/inference/world_pipeline.py")
+    ns = extract_functions(wp, {"_tile_seed", "gaussian_noise_patch", "linear_weight_window"},
+                           {"np": np, "torch": torch, "fill_standard_normal": pr.fill_standard_normal, "standard_normal": pr.standard_normal,
+                            "mp_concat": mp_concat, "MOCK": False})
+    extract_methods(wp, "WorldPipeline", {"_process_latent_conditioning", "_latent_inference"}, ns)
+    cfg = tiny_config(64, 1)
+    mb = _ref_model(cfg, synth_state_dict(cfg, seed=77))
+    self = types.SimpleNamespace(_dtype=None, device="cpu", seed=1234, log_mode="quiet", base_model=mb, torch_compile=False)
+    self._process_latent_conditioning = lambda *a, **k: ns["_process_latent_conditioning"](self, *a, **k)
+    means = torch.tensor([14.99, 11.65, 15.87, 619.26, 833.12, 69.40, 0.66]); stds = torch.tensor([21.72, 21.78, 10.40, 452.29, 738.09, 34.59, 0.47])
+    hist = torch.tensor([[0.1, 0.3, 0.2, 0.25, 0.15]])
+    out = {"cond_means": means.numpy(), "cond_stds": stds.numpy(), "histogram_raw": hist.numpy()}
+    # ---- conditioning vectors
+    c1 = torch.from_numpy(pr.standard_normal(90, (1, 7, 4, 4))) * stds.view(1, -1, 1, 1) + means.view(1, -1, 1, 1)
+    c1[0, 0, 1, 2] = float("nan"); c1[0, 3, 1, 1] = float("nan"); c1[0, 6, 0, 0] = float("nan")
+    out["plc_in_n1"] = c1.numpy().copy()
+    out["plc_out_n1"] = ns["_process_latent_conditioning"](self, c1.clone(), hist, means, stds, torch.tensor(0.0), seed_offset=3 * 65536 - 2).numpy()
+    c3 = torch.from_numpy(pr.standard_normal(91, (3, 7, 4, 4))) * stds.view(1, -1, 1, 1) + means.view(1, -1, 1, 1)
+    c3[0, 2, 1, 1] = float("nan"); c3[1, 0, 0, 0] = float("nan"); c3[2, 2, 1, 2] = float("nan"); c3[2, 5, 2, 2] = float("nan"); c3[2, 4, 0, 0] = float("nan")
+    out["plc_in_n3"] = c3.numpy().copy()
+    out["plc_out_n3"] = ns["_process_latent_conditioning"](self, c3.clone(), hist.expand(3, -1), means, stds, torch.zeros(3), seed_offset=7).numpy()
+    # ---- latent windows: phase 0 (no previous sample) and a later phase (packed previous sums), two window contexts
+    sched = EDMDPMSolverMultistepScheduler(sigma_min=0.002, sigma_max=80, sigma_data=0.5)
+    sched.set_timesteps(20)
+    w = ns["linear_weight_window"](64, "cpu", torch.float32)
+    ctxs = [(0, 2, -3), (0, -1, 0)]
+    conds = []
+    for k in range(2):   # packed coarse windows (7,4,4): 6 value channels * weight, weight
+        v = torch.from_numpy(pr.standard_normal(92 + k, (6, 4, 4))) * stds[:6].view(-1, 1, 1) + means[:6].view(-1, 1, 1)
+        ww = torch.from_numpy(pr.standard_normal(95 + k, (1, 4, 4))).abs() + 0.5
+        conds.append(torch.cat([v * ww, ww], dim=0))
+    conds[1][2, 1, 1] = float("nan")
+    out["latent_cond_windows"] = torch.stack(conds).numpy()
+    t0 = torch.atan(sched.sigmas[0] / sched.config.sigma_data)
+    with torch.no_grad():
+        o0 = ns["_latent_inference"](self, ctxs, None, [c.clone() for c in conds], t0, sched, w, hist, means, stds, seed_offset=5819)
+        out["latent_phase0"] = torch.stack(o0).numpy()
+        t1 = torch.arctan(torch.tensor(0.35) / 0.5)
+        o1 = ns["_latent_inference"](self, ctxs, [o.clone() for o in o0], [c.clone() for c in conds], t1, sched, w, hist, means, stds, seed_offset=5820)
+        out["latent_phase1_from_phase0_windows"] = torch.stack(o1).numpy()
+    save("latent_glue", **out)
+
+
+ALL = dict(latent_glue=gen_latent_glue, stage_glue=gen_stage_glue, stages=gen_stages, rng=gen_rng, geometry=gen_geometry, schedule=gen_schedule, unet=gen_unet, sampling=gen_sampling)
 
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden generation needs the reference checkout"

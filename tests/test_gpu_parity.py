@@ -531,3 +531,78 @@ def test_coarse_and_decoder_stage_builders_vs_reference_golden(td, orc, golden):
     out2 = ds2.f([(0, 2, -1)], [lat_win])[0]
     assert rel_rms(out2.numpy(), g["decoder_ctx_0_2_m1_two_phases"]) < 1e-5
     md.close()
+
+
+def test_latent_glue_vs_reference_golden(td, orc, golden):
+    """process_latent_conditioning (NaN handling, engine-side portable-RNG fill) and the per-window latent arithmetic of
+    build_latent_stage(coarse=...) against the reference's own _process_latent_conditioning / _latent_inference outputs."""
+    from oracle.unet import tiny_config
+    from terrain_diffusion_amd.sampling import process_latent_conditioning
+    from terrain_diffusion_amd.pipeline import build_latent_stage
+    from terrain_diffusion_amd.infinite_tensor import InfiniteTensor, TensorWindow
+    U = orc["unet"]
+    g = golden("latent_glue")
+    means, stds, hist = g["cond_means"], g["cond_stds"], torch.from_numpy(g["histogram_raw"])
+    o1 = process_latent_conditioning(torch.from_numpy(g["plc_in_n1"]), hist, means, stds, 0.0, seed=1234, seed_offset=3 * 65536 - 2)
+    assert np.allclose(o1.numpy(), g["plc_out_n1"], rtol=1e-6, atol=1e-6)
+    o3 = process_latent_conditioning(torch.from_numpy(g["plc_in_n3"]), hist.expand(3, -1), means, stds, torch.zeros(3), seed=1234, seed_offset=7)
+    assert np.allclose(o3.numpy(), g["plc_out_n3"], rtol=1e-6, atol=2e-6)      # the RNG-filled entries are <= 1 ulp from numba's
+    cfg = tiny_config(64, 1)
+    m = td.EDMUnet2D(**cfg, dtype="fp32").load_state_dict(U.synth_state_dict(cfg, seed=77))
+    dummy = InfiniteTensor((7, None, None), lambda ctx: torch.ones(7, 4, 4), TensorWindow(size=(7, 4, 4), stride=(7, 4, 4)), tensor_id="coarse_dummy")
+    lat = build_latent_stage(m, seed=1234, coarse=dummy, histogram_raw=hist, cond_means=means, cond_stds=stds)
+    ctxs = [(0, 2, -3), (0, -1, 0)]
+    conds = list(torch.from_numpy(g["latent_cond_windows"]))
+    t0 = float(torch.atan(torch.tensor(80.0) / 0.5))
+    p0 = lat.infer(0, t0, ctxs, None, conds)
+    assert rel_rms(torch.stack(p0).numpy(), g["latent_phase0"]) < 1e-5
+    p1 = lat.infer(1, float(torch.arctan(torch.tensor(0.35) / 0.5)), ctxs, list(torch.from_numpy(g["latent_phase0"])), conds)
+    assert rel_rms(torch.stack(p1).numpy(), g["latent_phase1_from_phase0_windows"]) < 1e-5
+    m.close()
+
+
+def test_cascade_coarse_latent_decoder_vs_oracle_chain(td, orc):
+    """The three engine-backed stages chained exactly as WorldPipeline wires them (coarse (7,*,*) -> latent windows through the
+    (7,4,4)/offset -1 conditioning window, two blended trig-flow phases -> decoder through the (6,T/8,T/8) window), against the same
+    InfiniteTensor graph whose window functions are the CPU oracle's (oracle/stages.py, pinned to the reference window by window).
+    fp32 engine mode; a 40x40 region of the decoder output pulls 4 coarse, 34 latent and 4 decoder windows through the graph."""
+    from oracle import stages
+    from oracle.unet import COARSE_CONFIG, DECODER_CONFIG, tiny_config
+    from terrain_diffusion_amd.pipeline import build_coarse_stage, build_latent_stage, build_decoder_stage
+    from terrain_diffusion_amd.infinite_tensor import InfiniteTensor, TensorWindow
+    U = orc["unet"]
+    seed = 4242
+    means6 = [0.3, -0.2, 0.1, 0.0, 0.4, -0.1]; stds6 = [1.5, 0.8, 1.2, 0.9, 1.1, 0.7]; snr = [0.5, 0.4, 0.6, 0.3, 0.8]
+    hist = torch.tensor([[0.1, 0.3, 0.2, 0.25, 0.15]])
+    cm, cs_ = [0.2, 0.1, 0.0, -0.1, 0.3, 0.0, 0.66], [1.2, 1.1, 0.9, 1.0, 1.3, 0.8, 0.47]
+    bcfg = tiny_config(64, 1)
+    sdc, sdb, sdd = U.synth_state_dict(COARSE_CONFIG, seed=1), U.synth_state_dict(bcfg, seed=2), U.synth_state_dict(DECODER_CONFIG, seed=3)
+    # ---- engine graph
+    mc = td.EDMUnet2D(**COARSE_CONFIG, dtype="fp32").load_state_dict(sdc)
+    mb = td.EDMUnet2D(**bcfg, dtype="fp32").load_state_dict(sdb)
+    md = td.EDMUnet2D(**DECODER_CONFIG, dtype="fp32").load_state_dict(sdd)
+    coarse = build_coarse_stage(mc, td.EDMDPMSolverMultistepScheduler(), seed=seed, cond_map_fn=stages.synthetic_coarse_map, coarse_means=means6,
+                                coarse_stds=stds6, cond_snr=snr)
+    lat = build_latent_stage(mb, seed=seed, coarse=coarse, histogram_raw=hist, cond_means=cm, cond_stds=cs_)
+    dec = build_decoder_stage(md, lat, seed=seed, tile_size=64, tile_stride=48)
+    got = torch.as_tensor(dec[:, 4:44, 2:42])
+    # ---- the same graph on the oracle
+    oc, ob, od = U.OracleUnet(COARSE_CONFIG, sdc), U.OracleUnet(bcfg, sdb), U.OracleUnet(DECODER_CONFIG, sdd)
+    ocoarse = InfiniteTensor((7, None, None), lambda ctx: stages.coarse_inference(oc, ctx, seed=seed, cond_map_fn=stages.synthetic_coarse_map, means=means6,
+                             stds=stds6, cond_snr=snr), TensorWindow(size=(7, 64, 64), stride=(7, 48, 48)), tensor_id="o_coarse")
+    lwin, cwin = TensorWindow(size=(6, 64, 64), stride=(6, 32, 32)), TensorWindow(size=(7, 4, 4), stride=(7, 1, 1), offset=(0, -1, -1))
+    kw = dict(seed=seed, histogram_raw=hist, cond_means=cm, cond_stds=cs_)
+    t0, t1 = torch.atan(torch.tensor(80.0) / 0.5), torch.arctan(torch.tensor(0.35) / 0.5)
+    ol0 = InfiniteTensor((6, None, None), lambda ctx, c: stages.latent_inference(ob, [ctx], None, [c], t0, seed_offset=5819, **kw)[0], lwin,
+                         args=(ocoarse,), args_windows=(cwin,), tensor_id="o_lat0")
+    ol1 = InfiniteTensor((6, None, None), lambda ctx, s, c: stages.latent_inference(ob, [ctx], [s], [c], t1, seed_offset=5820, **kw)[0], lwin,
+                         args=(ol0, ocoarse), args_windows=(lwin, cwin), tensor_id="o_lat1")
+    odec = InfiniteTensor((2, None, None), lambda ctx, l: stages.decoder_inference(od, ctx, torch.as_tensor(l), seed=seed, tile_size=64, tile_stride=48),
+                          TensorWindow(size=(2, 64, 64), stride=(2, 48, 48)), args=(ol1,), args_windows=(TensorWindow(size=(6, 8, 8), stride=(6, 6, 6)),),
+                          tensor_id="o_dec")
+    ref = torch.as_tensor(odec[:, 4:44, 2:42])
+    assert got.shape == ref.shape == (2, 40, 40)
+    assert torch.equal(got[1], ref[1]) or torch.allclose(got[1], ref[1], rtol=1e-6, atol=1e-7)          # blend weights
+    assert rel_rms((got[0] / got[1]).numpy(), (ref[0] / ref[1]).numpy()) < 1e-4
+    for m_ in (mc, mb, md):
+        m_.close()

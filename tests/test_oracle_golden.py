@@ -248,3 +248,26 @@ def test_stage_glue_oracle_matches_reference(golden):
     t0 = torch.atan(torch.tensor(80.0) / 0.5)
     out2 = stages.decoder_inference(md, (0, 2, -1), lat, seed=1234, tile_size=64, tile_stride=48, t_list=[t0, torch.arctan(torch.tensor(0.065) / 0.5)]).numpy()
     assert rel_rms(out2, g["decoder_ctx_0_2_m1_two_phases"]) < 5e-6
+
+
+def test_latent_glue_oracle_matches_reference(golden):
+    """oracle/stages.py process_latent_conditioning (NaN handling + portable-RNG fill) and latent_inference against the reference's own
+    method bodies (tests/golden/make_golden.py::gen_latent_glue)."""
+    import torch
+    from oracle import stages
+    g = golden("latent_glue")
+    means, stds, hist = g["cond_means"], g["cond_stds"], torch.from_numpy(g["histogram_raw"])
+    o1 = stages.process_latent_conditioning(torch.from_numpy(g["plc_in_n1"]), hist, means, stds, torch.tensor(0.0), seed=1234, seed_offset=3 * 65536 - 2)
+    assert o1.shape == (1, 58) and np.allclose(o1.numpy(), g["plc_out_n1"], rtol=1e-6, atol=1e-6)
+    o3 = stages.process_latent_conditioning(torch.from_numpy(g["plc_in_n3"]), hist.expand(3, -1), means, stds, torch.zeros(3), seed=1234, seed_offset=7)
+    assert np.isfinite(g["plc_out_n3"]).all() and np.allclose(o3.numpy(), g["plc_out_n3"], rtol=1e-6, atol=1e-6)
+    cfg = tiny_config(64, 1)
+    m = OracleUnet(cfg, synth_state_dict(cfg, seed=77))
+    ctxs = [(0, 2, -3), (0, -1, 0)]
+    conds = list(torch.from_numpy(g["latent_cond_windows"]))
+    kw = dict(seed=1234, histogram_raw=hist, cond_means=means, cond_stds=stds)
+    t0 = torch.atan(torch.tensor(80.0) / 0.5)
+    p0 = stages.latent_inference(m, ctxs, None, conds, t0, seed_offset=5819, **kw)
+    assert rel_rms(torch.stack(p0).numpy(), g["latent_phase0"]) < 5e-6
+    p1 = stages.latent_inference(m, ctxs, list(torch.from_numpy(g["latent_phase0"])), conds, torch.arctan(torch.tensor(0.35) / 0.5), seed_offset=5820, **kw)
+    assert rel_rms(torch.stack(p1).numpy(), g["latent_phase1_from_phase0_windows"]) < 5e-6
