@@ -480,6 +480,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
                         unsigned a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
                         swap_halves(a0, b0); swap_halves(a1, b1);
                         *(u32x4*)(orow + j * 32 + m * 16) = u32x4{a0, a1, b0, b1};
+                        if (p.out2) {  // the consumer's mp_silu(scale * x), from the rounded value (== what its patch staging would compute)
+                            bf16x4 ga, gb;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { ga[e] = (__bf16)Elem<T>::silu((float)ha[e] * p.out2_scale); gb[e] = (__bf16)Elem<T>::silu((float)hb[e] * p.out2_scale); }
+                            const u32x2 qa = __builtin_bit_cast(u32x2, ga), qb = __builtin_bit_cast(u32x2, gb);
+                            unsigned c0 = qa[0], c1 = qa[1], d0 = qb[0], d1 = qb[1];
+                            swap_halves(c0, d0); swap_halves(c1, d1);
+                            *(u32x4*)((T*)p.out2 + (orow - (T*)p.out) + j * 32 + m * 16) = u32x4{c0, c1, d0, d1};
+                        }
                     }
                 }
             } else {

@@ -115,11 +115,23 @@ __device__ __forceinline__ float epilogue4(const ConvParams& p, int n, int y, in
         if constexpr (sizeof(T) == 4) {
             *(f32x4*)((float*)p.out + (size_t)pix * p.out_cstride + co) = v;
             ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            if (p.out2) {
+                f32x4 a;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] = Elem<T>::silu(v[k] * p.out2_scale);
+                *(f32x4*)((float*)p.out2 + (size_t)pix * p.out_cstride + co) = a;
+            }
         } else {
             bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
             *(bf16x4*)((__bf16*)p.out + (size_t)pix * p.out_cstride + co) = h;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { float f = (float)h[k]; ss += f * f; }
+            if (p.out2) {  // from the ROUNDED value: bit-identical to applying the activation while staging the consumer's patch
+                bf16x4 a;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] = (__bf16)Elem<T>::silu((float)h[k] * p.out2_scale);
+                *(bf16x4*)((__bf16*)p.out2 + (size_t)pix * p.out_cstride + co) = a;
+            }
         }
     }
     return ss;

@@ -9,6 +9,7 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <unordered_map>
 
 #include "../../include/td_engine.h"
 #include "td_device.h"
@@ -479,7 +480,7 @@ struct SegSpec { const Tensor* t; int C; int taps; int resample; int xform; floa
 static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
     char key[64];
     snprintf(key, sizeof key, "%d_%d_%d_%d%d%d_%lld", N, H, W, (int)u->eng->option("batch_invariant", 0), (int)u->eng->option("glds", 1),
-             (int)u->eng->option("splitk", 1), (long long)u->eng->option("glds_min_wgs", 96));
+             (int)u->eng->option("splitk", 1) + 2 * (int)u->eng->option("producer_act", 1), (long long)u->eng->option("glds_min_wgs", 96));
     auto it = u->plans.find(key);
     if (it != u->plans.end()) { *out = it->second.get(); return TD_OK; }
     if (N < 1 || N > 1023 || H > 1023 || W > 1023) return fail(TD_ERR_ARG, "batch/size out of range");
@@ -670,6 +671,32 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
     Tensor Ft;
     if ((rc = conv("out_conv", {{&cur, u->final_c, 9, 0, 0, 1.f}}, h, w, EPI_PLAIN, -1, nullptr, 0, false, 0.f, false, true, &Ft))) return rc;
     pl.F = (float*)Ft.ptr;
+    // Producer-side activation: a segment that takes mp_silu(scale * x) of a whole conv output (decoder blocks: the running tensor
+    // and the skip tensor of the concatenation) reads a second copy that the PRODUCER's epilogue writes already activated, instead of
+    // applying exp/rcp to every 16-byte piece of every halo patch in every cout-tile workgroup of the consumer.  One copy per
+    // producer (the first such consumer's scale); computed from the rounded output, so results are bit-identical to the in-kernel form.
+    if (u->eng->option("producer_act", 1)) {
+        std::unordered_map<const void*, size_t> producer;
+        for (size_t k = 0; k < pl.ops.size(); ++k)
+            if (pl.ops[k].kind == Op::CONV && !pl.ops[k].p.out_f32) producer[pl.ops[k].p.out] = k;
+        for (size_t j = 0; j < pl.ops.size(); ++j) {
+            if (pl.ops[j].kind != Op::CONV) continue;
+            ConvParams& c = pl.ops[j].p;
+            for (int i = 0; i < c.nseg; ++i) {
+                if (c.seg[i].xform != 1) continue;
+                auto it = producer.find(c.seg[i].src);
+                if (it == producer.end() || it->second >= j) continue;
+                ConvParams& q = pl.ops[it->second].p;
+                if (q.out2 && q.out2_scale != c.seg[i].scale) continue;
+                if (!q.out2) {
+                    void* b2;
+                    if ((rc = new_buf(pl, (size_t)q.N * q.H * q.W * q.out_cstride * es, &b2))) return rc;
+                    q.out2 = b2; q.out2_scale = c.seg[i].scale;
+                }
+                c.seg[i].src = q.out2; c.seg[i].xform = 0; c.seg[i].scale = 1.f;
+            }
+        }
+    }
     if (partial_bytes) {
         void* pp;
         if ((rc = new_buf(pl, partial_bytes, &pp))) return rc;

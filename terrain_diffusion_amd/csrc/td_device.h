@@ -46,6 +46,8 @@ struct ConvParams {
     float clip;           // <=0: no clip
     float* out_sumsq;     // [n_ntiles*WAVES_N][N*H*W] or null
     float* partial;       // split-K workspace [ksplit][N*H*W][CoutPad] fp32
+    void* out2;           // optional second output, same layout as out: mp_silu(out2_scale * out) -- the consumer's activation, done once here
+    float out2_scale;
 };
 
 struct SchedCoef {        // one DPM-Solver++ step, fp32 scalars computed on the host

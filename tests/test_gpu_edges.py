@@ -170,3 +170,28 @@ def test_forward_bitwise_repeatable_under_load(td):
     out = m(x[perm].contiguous(), t[perm.cpu()].contiguous(), [c[perm].contiguous()])
     assert torch.equal(out[perm], ref)
     m.close()
+
+
+def test_producer_side_activation_is_bit_identical(td):
+    """plan option producer_act (decoder-block inputs activated once in the producer's epilogue instead of during every patch
+    staging of the consumer) must not change a single bit, in bf16 and in fp32 mode."""
+    from oracle.unet import synth_state_dict, tiny_config
+    from terrain_diffusion_amd.engine import get_engine
+    eng = get_engine("cuda")
+    cfg = tiny_config(128, 2)
+    sd = synth_state_dict(cfg, seed=11)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn(12, 5, 64, 64, device="cuda", generator=g)
+    c = torch.randn(12, 58, device="cuda", generator=g)
+    t = torch.linspace(-0.5, 1.5, 12)
+    for dtype in ("bf16", "fp32"):
+        m = td.EDMUnet2D(**cfg, dtype=dtype).load_state_dict(sd)
+        try:
+            eng.set_option("producer_act", 1)
+            a = m(x, t, [c])
+            eng.set_option("producer_act", 0)
+            b = m(x, t, [c])
+        finally:
+            eng.set_option("producer_act", 1)
+        assert torch.equal(a, b), dtype
+        m.close()
