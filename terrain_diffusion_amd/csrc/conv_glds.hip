@@ -48,6 +48,14 @@ __device__ __forceinline__ void frag_pixel(int q0, int l31, int& img, int& ty, i
         img = q0 / TPIX;
         ty = (q0 % TPIX) / 16 + (g2 ? 1 : 0);
         tx = u;
+    } else if constexpr (TW == 8 && TD_REMAP_ON) {
+        // 8-wide tile, patch rows 12 pixels apart: the fragment is 4 tile rows x 8; group one takes the LEFT halves of the four rows
+        // (patch rows p, p+12, p+24, p+36 (+0..3): residues p+{0..3}, p+{12..15}, p+{8..11}, p+{4..7} mod 16), group two the right halves
+        const bool g2 = (l31 >= 4 && l31 < 12) || (l31 >= 16 && l31 < 20) || l31 >= 28;
+        const int u = g2 ? (l31 < 12 ? l31 - 4 : (l31 < 20 ? l31 - 8 : l31 - 16)) : (l31 < 4 ? l31 : (l31 < 16 ? l31 - 8 : l31 - 12));
+        img = q0 / TPIX;
+        ty = (q0 % TPIX) / 8 + (u >> 2);
+        tx = (u & 3) + (g2 ? 4 : 0);
     } else {
         const int q = q0 + l31, r = q % TPIX;
         img = q / TPIX; ty = r / TW; tx = r % TW;
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
     typedef __bf16 T;
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
     constexpr int TPIX = TH * TW, BM = NIMG * TPIX;
-    constexpr int PH = TH + 2, PW = TW + 2, PPI = PH * PW, NPATCH = NIMG * PPI;
+    constexpr int PH = TH + 2, PW = TW == 8 ? 12 : TW + 2, PPI = PH * PW, NPATCH = NIMG * PPI;  // 8-wide: 2 pad columns (see frag_pixel)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MT = WM / 32, NT = WN / 32;
     constexpr int CHUNK = 64, PER16 = 8;
     constexpr int A_ITERS = (NPATCH * 8 + NTHR - 1) / NTHR;
@@ -102,18 +110,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
 
     int bid = blockIdx.x;
     const int ntile = bid % p.n_ntiles; bid /= p.n_ntiles;
-    const int mtile = bid;
+    const int mtiles = p.tiles_x * p.tiles_y * p.img_groups;
+    const int mtile = bid % mtiles;
+    const int ksp = bid / mtiles;  // split-K index: this workgroup reduces K-groups [g0, g1) and leaves fp32 partials to the reduce kernel
     const int txi = mtile % p.tiles_x, tyi = (mtile / p.tiles_x) % p.tiles_y, ig = mtile / (p.tiles_x * p.tiles_y);
     const int n0 = ig * NIMG, y0 = tyi * TH, x0 = txi * TW, co0 = ntile * BN;
-
-    // total K-steps of this conv (ksplit == 1 in this flavour)
-    int nk = 0;
-    for (int s = 0; s < p.nseg; ++s) nk += (p.seg[s].C / CHUNK) * p.seg[s].taps;
+    const int g0 = (int)((long)ksp * p.kgroups / p.ksplit), g1 = (int)((long)(ksp + 1) * p.kgroups / p.ksplit);
+    int seg_first = 0, chunk_first = 0, kstep_first = 0;  // (segment, chunk) of K-group g0 and the K-step it starts at
+    {
+        int g = 0;
+        while (seg_first < p.nseg) {
+            const int nch = p.seg[seg_first].C / CHUNK;
+            if (g0 < g + nch) { chunk_first = g0 - g; kstep_first += chunk_first * p.seg[seg_first].taps; break; }
+            g += nch; kstep_first += nch * p.seg[seg_first].taps; ++seg_first;
+        }
+    }
 
     // ---- weight ring.  wnext is the (wave-uniform, SGPR) address of the next tile to fetch; every tap fetches the tile two K-steps
     // ahead UNCONDITIONALLY (the packed slab carries two K-steps of tail padding), so the loop has no tail tests and a fixed vmcnt.
-    const unsigned char* wnext = (const unsigned char*)p.wpack + (size_t)co0 * 128;
     const size_t wstep = (size_t)p.CoutPad * 128;
+    const unsigned char* wnext = (const unsigned char*)p.wpack + (size_t)co0 * 128 + (size_t)kstep_first * wstep;
     unsigned wvoff[NBI];
 #pragma unroll
     for (int i = 0; i < NBI; ++i) wvoff[i] = (unsigned)tid * 16u + (unsigned)i * NTHR * 16u;
@@ -136,7 +152,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
         const int e = tid + it * NTHR, pp = e >> 3;
         const int img = pp / PPI, r = pp % PPI, py = r / PW, px = r % PW;
         const int n = n0 + img, y = y0 + py - 1, x = x0 + px - 1;
-        const bool ok = (pp < NPATCH) && n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        const bool ok = (pp < NPATCH) && px < TW + 2 && n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W;  // px >= TW+2: pad columns
         const bool interior = py >= 1 && py <= TH && px >= 1 && px <= TW;
         a_coord[it] = ok ? ((n << 21) | (y << 11) | (x << 1) | (interior ? 1 : 0)) : -1;
     }
@@ -180,8 +196,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
             }                                                                                          \
         }                                                                                              \
     }
-    TD_SEG_BEGIN(0);
-    TD_LOAD_A(0);
+    TD_SEG_BEGIN(seg_first);
+    TD_LOAD_A(chunk_first);
 
     // ---- per-pixel 1/(eps + rms) of the pixel-normed source, for the patch pixels
     const float* rn_sumsq = nullptr; int rn_parts = 0, rn_Hs = 0, rn_Ws = 0, rn_res = 0; float rn_invc = 0.f;
@@ -356,8 +372,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
         TD_FRAG_MFMA(wfA_, xfA_);                                                                            \
         TD_FRAG_MFMA(wfB_, xfB_);                                                                            \
     }
-    for (int seg = 0; seg < p.nseg; ++seg) {
-        if (seg > 0) {  // first K-group of a later segment: its patch could not be prefetched (different source tensor / transform)
+    int gidx = g0;
+    for (int seg = seg_first; seg < p.nseg && gidx < g1; ++seg) {
+        if (seg > seg_first) {  // first K-group of a later segment: its patch could not be prefetched (different source tensor / transform)
             TD_SEG_BEGIN(seg);
             TD_LOAD_A(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -365,8 +382,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
             asm volatile("" ::: "memory");
             TD_STORE_A();                  // visible after the next tap's lgkmcnt(0) + barrier
         }
-        for (int chunk = 0; chunk < seg_nchunks; ++chunk) {
-            const bool has_next = chunk + 1 < seg_nchunks;
+        for (int chunk = (seg == seg_first ? chunk_first : 0); chunk < seg_nchunks && gidx < g1; ++chunk, ++gidx) {
+            const bool has_next = chunk + 1 < seg_nchunks && gidx + 1 < g1;
             if (seg_taps == 9) {  // slot == 0 here: the host orders 3x3 segments before 1x1 segments, and RING divides 9
 #ifndef TD_NO_PIPE
                 TD_GROUP_ENTRY();
@@ -430,6 +447,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
     // leaves as dwordx4 stores (the store tail is issue-bound: half the instructions, half the time; guide T21).  The residual is
     // fetched the same way in reverse (16-byte loads, then the same swap restores the MFMA layout).
     const bool wide = !p.out_f32 && (p.Cout & 7) == 0;
+    if (p.ksplit > 1) {  // raw fp32 partial sums [ksplit][pixel][CoutPad]; conv_splitk_reduce_kernel adds them in fixed order + epilogue
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            int img, ty, tx;
+            frag_pixel<TW, TPIX>(wm * WM + i * 32, l31, img, ty, tx);
+            const int n = n0 + img, y = y0 + ty, x = x0 + tx;
+            if (n < p.N && y < p.H && x < p.W) {
+                float* prow = p.partial + ((size_t)ksp * M + ((size_t)n * p.H + y) * p.W + x) * p.CoutPad + co0 + wn * WN + 4 * lh;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        *(f32x4*)(prow + j * 32 + rg * 8) = f32x4{acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]};
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         int img, ty, tx;
@@ -532,12 +566,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
 
 template <int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N>
 static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
-    constexpr int NPATCH = NIMG * (TH + 2) * (TW + 2);
+    constexpr int NPATCH = NIMG * (TH + 2) * (TW == 8 ? 12 : TW + 2);
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
     const size_t lds = (size_t)NPATCH * 144 + 3 * (size_t)(((BN * 128 + NTHR * 16 - 1) / (NTHR * 16)) * NTHR * 16) + NPATCH * 4;
     bool seen1 = false;  // the kernel's compile-time ring slots need every 3x3 segment to start on a multiple of 3 K-steps
     for (int s = 0; s < p.nseg; ++s) { if (p.seg[s].taps == 9 && seen1) return hipErrorInvalidValue; if (p.seg[s].taps != 9) seen1 = true; }
-    const int grid = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups;
+    const int grid = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * p.ksplit;
     auto kern = conv_glds_kernel<TH, TW, NIMG, BN, WAVES_M, WAVES_N>;
     static bool attr_set = false;  // one per instantiation
     if (!attr_set) {
@@ -546,7 +580,13 @@ static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES_M * WAVES_N), lds, st, p);
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && p.ksplit > 1) {
+        const size_t W_ = (size_t)p.N * p.H * p.W * ((p.CoutPad + 255) / 256);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel<__bf16>, dim3((unsigned)((W_ + 3) / 4)), dim3(256), 0, st, p);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 // Tile configurations (variant):

@@ -558,6 +558,11 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
                 const int TH2 = variant ? 8 : (op.narrow ? 8 : 16), NIMG2 = op.narrow ? (variant ? 2 : 4) : 1;
                 p.tiles_x = (w + TW2 - 1) / TW2; p.tiles_y = (h + TH2 - 1) / TH2; p.img_groups = (N + NIMG2 - 1) / NIMG2;
                 p.n_ntiles = cw.cout_pad / bn2; p.ksplit = 1;
+                // too few workgroups to give every SIMD two waves (8x8 level of a 64-tile batch, small batches): split K, the fp32
+                // partials are summed in fixed order by conv_splitk_reduce_kernel (not in batch_invariant mode: the K order changes)
+                const int64_t wgs = mt2 * p.n_ntiles, slots = variant ? 512 : 256;
+                if (!inv && use_splitk && u->eng->option("glds_splitk", 1) && kgroups >= 4 && wgs * 2 <= slots)
+                    p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(8, kgroups / 2), slots / wgs);
             }
         }
         if (op.flavor == 0) {
