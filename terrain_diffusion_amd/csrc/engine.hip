@@ -480,7 +480,7 @@ struct SegSpec { const Tensor* t; int C; int taps; int resample; int xform; floa
 static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
     char key[64];
     snprintf(key, sizeof key, "%d_%d_%d_%d%d%d_%lld", N, H, W, (int)u->eng->option("batch_invariant", 0), (int)u->eng->option("glds", 1),
-             (int)u->eng->option("splitk", 1) + 2 * (int)u->eng->option("producer_act", 1), (long long)u->eng->option("glds_min_wgs", 96));
+             (int)u->eng->option("splitk", 1) + 2 * (int)u->eng->option("producer_act", 1), (long long)u->eng->option("glds_min_wgs", 8));
     auto it = u->plans.find(key);
     if (it != u->plans.end()) { *out = it->second.get(); return TD_OK; }
     if (N < 1 || N > 1023 || H > 1023 || W > 1023) return fail(TD_ERR_ARG, "batch/size out of range");
@@ -553,7 +553,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
             // "batch_invariant": kernel flavour and K order do not depend on the batch size (no split-K, LDS-DMA flavour whenever it
             // applies), so a window's result is bit-identical whatever other windows share its batch / GPU.
             const bool inv = u->eng->option("batch_invariant", 0) != 0;
-            if (u->bf16 && bn2 && u->eng->option("glds", 1) && (inv || mt2 * (cw.cout_pad / bn2) >= u->eng->option("glds_min_wgs", 96))) {
+            if (u->bf16 && bn2 && u->eng->option("glds", 1) && (inv || mt2 * (cw.cout_pad / bn2) >= u->eng->option("glds_min_wgs", 8))) {
                 op.flavor = 2; op.bn = bn2; op.glds_variant = variant;
                 const int TH2 = variant ? 8 : (op.narrow ? 8 : 16), NIMG2 = op.narrow ? (variant ? 2 : 4) : 1;
                 p.tiles_x = (w + TW2 - 1) / TW2; p.tiles_y = (h + TH2 - 1) / TH2; p.img_groups = (N + NIMG2 - 1) / NIMG2;
@@ -562,7 +562,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
                 // partials are summed in fixed order by conv_splitk_reduce_kernel (not in batch_invariant mode: the K order changes)
                 const int64_t wgs = mt2 * p.n_ntiles, slots = variant ? 512 : 256;
                 if (!inv && use_splitk && u->eng->option("glds_splitk", 1) && kgroups >= 4 && wgs * 2 <= slots)
-                    p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(8, kgroups / 2), slots / wgs);
+                    p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(u->eng->option("glds_splitk_max", 16), kgroups / 2), slots / wgs);
             }
         }
         if (op.flavor == 0) {
