@@ -562,7 +562,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
                 // partials are summed in fixed order by conv_splitk_reduce_kernel (not in batch_invariant mode: the K order changes)
                 const int64_t wgs = mt2 * p.n_ntiles, slots = variant ? 512 : 256;
                 if (!inv && use_splitk && u->eng->option("glds_splitk", 1) && kgroups >= 4 && wgs * 2 <= slots)
-                    p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(u->eng->option("glds_splitk_max", 16), kgroups / 2), slots / wgs);
+                    p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(u->eng->option("glds_splitk_max", 32), kgroups / std::max<int64_t>(1, u->eng->option("glds_splitk_min_groups", 1))), slots / wgs);
             }
         }
         if (op.flavor == 0) {
