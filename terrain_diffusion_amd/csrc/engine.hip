@@ -49,7 +49,9 @@ struct DevBuf {
         if (p) { (void)hipFree(p); p = nullptr; }
         bytes = n ? n : 16;
         hipError_t e = hipMalloc(&p, bytes);
-        if (e == hipSuccess && zero) e = hipMemset(p, 0, bytes);
+        // hipMemset on device memory is asynchronous and runs on the NULL stream, which the engine's non-blocking stream does not wait
+        // for: without the synchronise a kernel launched right after could be overtaken by the zero fill (allocations are setup-time)
+        if (e == hipSuccess && zero) { e = hipMemset(p, 0, bytes); if (e == hipSuccess) e = hipDeviceSynchronize(); }
         return e;
     }
 };
