@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--edm-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-tile latency leg (keeps rocprofv3 counter passes to the batched steps only)")
     args = ap.parse_args()
 
     import torch
@@ -177,14 +178,14 @@ def main():
                 # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled per the
                 # MI355X guide's gfx950 correction, + WRITE_SIZE); not re-measured live (PMC collection needs rocprofv3)
                 tj = json.load(open(tpath))["kernels"]
-                ks_ = [v for k_, v in tj.items() if "conv_glds_kernel<16" in k_]
+                ks_ = [v for k_, v in tj.items() if "conv_glds_kernel" in k_ and v.get("dispatches")]
                 n_ = sum(v["dispatches"] for v in ks_)
                 roof["traffic"] = round(sum(v["dispatches"] * (v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]) for v in ks_) / n_)
                 roof["traffic_source"] = "profiles/r01_hbm_traffic_and_mfma_util.json"
         else:
             roof.update({"achieved": roof["end_to_end_achieved"], "frac": roof["end_to_end_frac"]})
         result["roofline"] = roof
-        if args.workload == "tiles":
+        if args.workload == "tiles" and not args.no_latency:
             # secondary number: latency of ONE tile through the same path (batch 1: launch/HBM-latency bound, not MFMA bound)
             one_step(20_000, 1); sync()
             l0 = time.perf_counter()

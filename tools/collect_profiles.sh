@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_new; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile"
+BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-latency"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
   tag=$(echo $c | cut -d' ' -f1)
@@ -46,7 +46,7 @@ for k, cs in cnt.items():
         mfma = g("SQ_INSTS_VALU_MFMA_MOPS_BF16") / 64.0   # MOPS counter: 64 per 32x32x16 bf16 MFMA (32768 flop / 512)
         e["valu_per_mfma"] = round((g("SQ_INSTS_VALU") - mfma) / mfma, 2) if mfma else None
     kern[k] = e
-json.dump({"note": "rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile` (batch 64 x 20 solver steps per bench step). FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced stream); WRITE_SIZE uncalibrated; units KB -> bytes x1024. mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs).", "kernels": kern}, open(out + "/hbm_traffic_and_mfma_util.json", "w"), indent=1)
+json.dump({"note": "rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-latency` (batch 64 x 20 solver steps per bench step). FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced stream); WRITE_SIZE uncalibrated; units KB -> bytes x1024. mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs).", "kernels": kern}, open(out + "/hbm_traffic_and_mfma_util.json", "w"), indent=1)
 print(open(out + "/kernel_trace_summary.csv").read()[:1500])
 PY
 rm -rf $OUT/kt $OUT/pmc_*/  # raw traces are large; the summaries are what gets committed
