@@ -1,16 +1,17 @@
-// Throughput flavour of the implicit-GEMM convolution (bf16, gfx950): used when a layer has enough output pixels to fill the chip.
+// LDS-DMA flavour of the implicit-GEMM convolution (bf16, gfx950): the kernel behind almost every conv of a bf16 forward.
 // Same maths / parameter block / fused prologues and epilogues as conv_igemm.hip; what differs is the pipeline:
-//   * weights stream HBM/L2 -> LDS with `global_load_lds_dwordx4` (LDS-DMA): no VGPR staging, no ds_write, into a 3-slot ring
-//     that runs two K-steps ahead of the MFMAs behind COUNTED `s_waitcnt vmcnt(N)` and raw `s_barrier`s (never drained to 0 in
-//     the steady state) — MI355X guide §5 "Pipelining across barriers" / T3+T4;
-//   * 8 waves per workgroup (2 per SIMD) on a 256-pixel x BN-cout tile; each wave owns 64 pixels x BN/2 couts of
-//     v_mfma_f32_32x32x16_bf16 tiles, so one weight tile is shared by 256 pixels and one activation patch by BN couts;
+//   * weights stream HBM/L2 -> LDS with `global_load_lds_dwordx4` (LDS-DMA: no VGPR staging, no ds_write) into a 3-slot ring, one
+//     tile ahead of the tap that uses it, behind COUNTED `s_waitcnt vmcnt(N)` / `lgkmcnt(N)` and raw `s_barrier`s; the slab is
+//     stored pre-swizzled in HBM and copied linearly (the LDS destination of an LDS-DMA is wave-uniform base + lane*16);
+//   * 8 waves x 256 pixels or 4 waves x 128 pixels per workgroup, BN = 96/128 couts; each wave owns a 64x64 (or 32x96) block of
+//     v_mfma_f32_32x32x16_bf16 tiles, so one weight tile is shared by all pixels and one activation patch by all couts;
 //   * the activation halo patch ((TH+2)x(TW+2) pixels x 64 channels) is fetched one K-group ahead into registers, transformed
-//     (pixel-norm / mp_silu) and written to LDS once per 9 taps;
-//   * LDS rows are 128 B with the 16-byte slot index XOR-ed by ((row >> 1) & 7): conflict-free for the 32-row ds_read_b128
-//     fragments of the 32x32x16 MFMA (and for the 16-row fragments of conv_igemm.hip).
-// The LDS destination of an LDS-DMA is wave-uniform base + lane*16, so the packed weight slab is stored pre-swizzled in HBM and
-// copied linearly (guide rule 21: swizzle on the source side).
+//     where the producer could not (pixel-norm + mp_silu) and written to LDS once per 9 taps, rows PADDED to 144 bytes;
+//   * the tap loop has no VALU: every fragment address is "lane base + compile-time (slot, tap, k-step) offset" (ds_read offset
+//     field), the lane -> pixel map makes every ds_read_b128 lane group conflict-free, and the loop is software-pipelined ACROSS
+//     taps (mid-tap barrier, next tap's first fragments requested behind the current MFMAs);
+//   * bf16 results leave as dwordx4 stores after v_permlane32_swap pairs; optional pre-activated second output; split-K.
+// DESIGN.md §4 has the measurements behind each of these choices and the list of variants that were tried and dropped.
 #include "td_device.h"
 
 namespace td {
@@ -247,11 +248,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
     TD_T(tr_pro);
 
 #define TD_TOFF(T) ((((T) / 3) * PW + ((T) % 3)) * PITCH)
-#ifdef TD_STAGGER  // the two waves of a SIMD (w, w+4) issue their LDS-DMA pieces at different points of the tap
-    const bool glds_early = (wave & 4) == 0;
-#else
-    const bool glds_early = true;
-#endif
     int slot = 0;  // ring slot of the current K-step; compile-time inside a 9-tap group (RING divides 9), tracked for 1x1 segments
     u32x4 wfA_[NT], xfA_[MT], wfB_[NT], xfB_[MT];
 #define TD_FRAG_READ(WF, XF, SLOT, KS, TOFF)                                                                 \
@@ -265,49 +261,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
             _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                \
                 acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WF[j_]), __builtin_bit_cast(bf16x8, XF[i_]), acc[i_][j_], 0, 0, 0); \
     }
-    // pin the issue order inside a tap to the source order (two k-steps of fragments in flight ahead of the MFMAs that use them);
-    // left alone, hipcc sinks the reads next to their consumers to save registers and exposes the LDS latency 4x per tap
-#ifdef TD_NO_SCHED
-#define TD_SCHED_TAP()
-#else
-#define TD_SCHED_TAP()                                                                                       \
-    {                                                                                                        \
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (NT + MT), 0);                                       \
-        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
-        __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);                                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
-        __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);                                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * NT, 0);                                         \
-    }
-#endif
-    // PEND: the next group's A_ITERS patch loads were issued after the tile that is in flight (taps 1 and 2 of a 9-tap group);
-    // vm ops retire in order, so "tile k has landed" == "at most <what was issued after it> is outstanding"
-#define TD_TAP(TAPIDX, SLOT, TOFF, PEND)                                                                     \
-    {                                                                                                        \
-        TD_T(tA_);                                                                                           \
-        if ((PEND) && has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI + A_ITERS) : "memory");         \
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI) : "memory");                                      \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
-        __builtin_amdgcn_s_barrier();                                                                        \
-        asm volatile("" ::: "memory");                                                                       \
-        TD_T(tB_); TD_TACC(tr_wait, tA_, tB_);                                                               \
-        if ((TAPIDX) == 4 && has_next) { /* the loads have retired (tap 3's wait): tell the compiler here, so that its own  \
-            conservative vmcnt(0) for them lands where only a long-issued tile is in flight, not at the restage */ \
-            _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) asm volatile("" : "+v"(av[it_]));      \
-        }                                                                                                    \
-        TD_ABL_BLOAD(TD_GLDS_B(((SLOT) + 2) % RING));                                                        \
-        TD_ABL_BSTORE(if ((TAPIDX) == 0 && has_next) TD_LOAD_A(chunk + 1));                                  \
-        TD_FRAG_READ(wfA_, xfA_, SLOT, 0, TOFF);                                                             \
-        TD_FRAG_READ(wfB_, xfB_, SLOT, 1, TOFF);                                                             \
-        TD_FRAG_MFMA(wfA_, xfA_);                                                                            \
-        TD_FRAG_READ(wfA_, xfA_, SLOT, 2, TOFF);                                                             \
-        TD_FRAG_MFMA(wfB_, xfB_);                                                                            \
-        TD_FRAG_READ(wfB_, xfB_, SLOT, 3, TOFF);                                                             \
-        TD_FRAG_MFMA(wfA_, xfA_);                                                                            \
-        TD_FRAG_MFMA(wfB_, xfB_);                                                                            \
-        TD_SCHED_TAP();                                                                                      \
-    }
-    // Pipelined form (TD_PIPE): the tap's barrier sits between k-steps 1 and 2 and does NOT drain the LDS queue; the next tap's first
+    // The tap's barrier sits between k-steps 1 and 2 and does NOT drain the LDS queue; the next tap's first
     // two k-steps of fragments are requested behind this tap's last MFMAs, so no fragment read is ever waited for right after
     // it was issued.  Passing barrier(k): weight tile k+1 is visible, nobody reads tile k-1 any more (its slot takes tile k+2).
 #define TD_TAPP(TAPIDX, SLOT, TOFF, TOFF_NEXT)                                                               \
@@ -332,13 +286,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
         if ((TAPIDX) == 3 && has_next) {                                                                     \
             _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) asm volatile("" : "+v"(av[it_]));      \
         }                                                                                                    \
-        if (glds_early) { TD_ABL_BLOAD(TD_GLDS_B(((SLOT) + 2) % RING)); }                                    \
+        TD_ABL_BLOAD(TD_GLDS_B(((SLOT) + 2) % RING));                                                        \
         if ((TAPIDX) == 0 && has_next) TD_LOAD_A(chunk + 1);                                                 \
         TD_FRAG_MFMA(wfA_, xfA_);                                                                            \
         if ((TAPIDX) < 8) TD_FRAG_READ(wfA_, xfA_, ((SLOT) + 1) % RING, 0, TOFF_NEXT);                       \
         TD_FRAG_MFMA(wfB_, xfB_);                                                                            \
         if ((TAPIDX) < 8) TD_FRAG_READ(wfB_, xfB_, ((SLOT) + 1) % RING, 1, TOFF_NEXT);                       \
-        if (!glds_early) { TD_ABL_BLOAD(TD_GLDS_B(((SLOT) + 2) % RING)); }                                   \
         __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
         if ((TAPIDX) < 8) __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);                           \
         __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
@@ -385,16 +338,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
         for (int chunk = (seg == seg_first ? chunk_first : 0); chunk < seg_nchunks && gidx < g1; ++chunk, ++gidx) {
             const bool has_next = chunk + 1 < seg_nchunks && gidx + 1 < g1;
             if (seg_taps == 9) {  // slot == 0 here: the host orders 3x3 segments before 1x1 segments, and RING divides 9
-#ifndef TD_NO_PIPE
                 TD_GROUP_ENTRY();
                 TD_TAPP(0, 0, TD_TOFF(0), TD_TOFF(1)); TD_TAPP(1, 1, TD_TOFF(1), TD_TOFF(2)); TD_TAPP(2, 2, TD_TOFF(2), TD_TOFF(3));
                 TD_TAPP(3, 0, TD_TOFF(3), TD_TOFF(4)); TD_TAPP(4, 1, TD_TOFF(4), TD_TOFF(5)); TD_TAPP(5, 2, TD_TOFF(5), TD_TOFF(6));
                 TD_TAPP(6, 0, TD_TOFF(6), TD_TOFF(7)); TD_TAPP(7, 1, TD_TOFF(7), TD_TOFF(8)); TD_TAPP(8, 2, TD_TOFF(8), TD_TOFF(8));
-#else
-                TD_TAP(0, 0, TD_TOFF(0), false); TD_TAP(1, 1, TD_TOFF(1), true); TD_TAP(2, 2, TD_TOFF(2), true);
-                TD_TAP(3, 0, TD_TOFF(3), false); TD_TAP(4, 1, TD_TOFF(4), false); TD_TAP(5, 2, TD_TOFF(5), false);
-                TD_TAP(6, 0, TD_TOFF(6), false); TD_TAP(7, 1, TD_TOFF(7), false); TD_TAP(8, 2, TD_TOFF(8), false);
-#endif
             } else {  // centre tap only
                 if (slot == 0) TD_TAP1(0, TD_TOFF(4)) else if (slot == 1) TD_TAP1(1, TD_TOFF(4)) else TD_TAP1(2, TD_TOFF(4));
             }
@@ -414,8 +361,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two over-fetched tail tiles must not land in a successor's LDS
 #undef TD_TOFF
-#undef TD_TAP
-#undef TD_SCHED_TAP
 #undef TD_TAP1
 #undef TD_TAPP
 #undef TD_GROUP_ENTRY

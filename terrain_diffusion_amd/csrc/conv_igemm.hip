@@ -190,11 +190,8 @@ __device__ __forceinline__ void mfma_tap(const unsigned char* __restrict__ sa, c
     }
 }
 
-// FLAVOR 0 ("tap"): one weight tile per K-step, double-buffered, one barrier per tap — for large pixel counts.
-// FLAVOR 1 ("stream"): all 9 tap tiles of a K-group staged at once (next group's 9 tiles + patch prefetched into registers while
-//   the current group multiplies), two barriers per group — for small pixel counts (batch 1), where each workgroup is bound by
-//   the latency of streaming its own slice of the weights from HBM.
-template <typename T, int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N, int FLAVOR>
+// One weight tile per K-step, register-staged and double-buffered in LDS, one barrier per tap; split-K over K-groups.
+template <typename T, int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(const ConvParams p) {
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
     constexpr int TPIX = TH * TW;
@@ -208,7 +205,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     static_assert(BM % (16 * WAVES_M) == 0 && BN % (16 * WAVES_N) == 0 && (BN * 8) % NTHR == 0, "tile shape");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NA = FLAVOR == 0 ? 2 : 1, NB = FLAVOR == 0 ? 2 : 9, BR = FLAVOR == 0 ? 1 : 9;
+    constexpr int NA = 2, NB = 2, BR = 1;
     unsigned char* s_a = smem;                        // activation-patch buffer(s)
     unsigned char* s_b = smem + NA * A_BYTES;         // weight-tile buffers
     float* s_rn = (float*)(s_b + NB * B_BYTES);
@@ -246,23 +243,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
         const u32x4* wsrc_ = (const u32x4*)p.wpack + ((size_t)ks_ * p.CoutPad + co0) * 8 + tid;        \
         _Pragma("unroll") for (int i_ = 0; i_ < B_ITERS; ++i_) DST[i_] = wsrc_[i_ * NTHR];             \
     }
-#define TD_LOAD_B_GROUP(KS, TAPS)                                                                      \
-    {                                                                                                  \
-        _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_)                                               \
-            if (t_ < (TAPS)) {                                                                         \
-                const u32x4* wsrc_ = (const u32x4*)p.wpack + ((size_t)((KS) + t_) * p.CoutPad + co0) * 8 + tid; \
-                _Pragma("unroll") for (int i_ = 0; i_ < B_ITERS; ++i_) breg[t_ * B_ITERS + i_] = wsrc_[i_ * NTHR]; \
-            }                                                                                          \
-    }
-#define TD_STORE_B_GROUP(TAPS)                                                                         \
-    {                                                                                                  \
-        _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_)                                               \
-            if (t_ < (TAPS)) {                                                                         \
-                _Pragma("unroll") for (int i_ = 0; i_ < B_ITERS; ++i_)                                 \
-                    *(u32x4*)(s_b + t_ * B_BYTES + (tid + i_ * NTHR) * 16) = breg[t_ * B_ITERS + i_];  \
-            }                                                                                          \
-    }
-    if constexpr (FLAVOR == 0) { TD_LOAD_B(breg, kstep); } else { TD_LOAD_B_GROUP(kstep, p.seg[seg].taps); }
+    TD_LOAD_B(breg, kstep);
 
     // ---- per-thread staging coordinates (constant over the K loop): packed (n, y, x, interior) or -1
     int a_coord[A_ITERS];
@@ -351,39 +332,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
 
     __syncthreads();  // s_rn visible
     if (g0 < g1) TD_STORE_A(seg, 0);
-    if constexpr (FLAVOR == 1) {
-        if (g0 < g1) TD_STORE_B_GROUP(p.seg[seg].taps);
-        for (int g = g0; g < g1; ++g) {
-            const int taps = p.seg[seg].taps;
-            int nseg_ = seg, nchunk_ = chunk + 1;
-            if (nchunk_ == p.seg[seg].C / CHUNK) { nchunk_ = 0; ++nseg_; }
-            const bool has_next = g + 1 < g1;
-            kstep += taps;
-            if (has_next) {  // next group's 9 weight tiles and patch fly while this group multiplies
-                TD_LOAD_B_GROUP(kstep, p.seg[nseg_].taps);
-                TD_LOAD_A(nseg_, nchunk_);
-            }
-            __syncthreads();
-            if (taps == 9) {
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) mfma_tap<T, MT, NTL>(s_a, s_b + tap * B_BYTES, base_pp, nloc, (tap / 3 - 1) * PW + (tap % 3 - 1), lg, acc);
-            } else {
-                mfma_tap<T, MT, NTL>(s_a, s_b, base_pp, nloc, 0, lg, acc);
-            }
-            if (has_next) {
-                __syncthreads();
-                TD_STORE_A(nseg_, 0);
-                TD_STORE_B_GROUP(p.seg[nseg_].taps);
-            }
-            if constexpr (TWO_LEVEL) {
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NTL; ++j) { tot[i][j] += acc[i][j]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            }
-            seg = nseg_; chunk = nchunk_;
-        }
-    } else {
     int abuf = 0, bbuf = 0;
 
     for (int g = g0; g < g1; ++g) {
@@ -420,13 +368,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
         }
         seg = nseg_; chunk = nchunk_;
     }
-    }
 #undef TD_TAP
 #undef TD_LOAD_A
 #undef TD_STORE_A
 #undef TD_LOAD_B
-#undef TD_LOAD_B_GROUP
-#undef TD_STORE_B_GROUP
     if constexpr (TWO_LEVEL) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -521,13 +466,13 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
 }
 
 // ------------------------------------------------------------------------------------------ host launcher
-template <typename T, int TH, int TW, int NIMG, int BN, int FLAVOR>
+template <typename T, int TH, int TW, int NIMG, int BN>
 static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
     constexpr int WAVES_M = 2, WAVES_N = 2;
     constexpr int NPATCH = NIMG * (TH + 2) * (TW + 2);
-    size_t lds = (size_t)(FLAVOR == 0 ? 2 : 1) * NPATCH * 128 + (FLAVOR == 0 ? 2 : 9) * BN * 128 + NPATCH * 4;
+    size_t lds = (size_t)2 * NPATCH * 128 + 2 * BN * 128 + NPATCH * 4;
     int grid = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * p.ksplit;
-    auto kern = conv_igemm_kernel<T, TH, TW, NIMG, BN, WAVES_M, WAVES_N, FLAVOR>;
+    auto kern = conv_igemm_kernel<T, TH, TW, NIMG, BN, WAVES_M, WAVES_N>;
     if (lds > 65536) {
         static bool attr_set = false;  // per instantiation
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
@@ -550,15 +495,15 @@ static hipError_t launch_t(const ConvParams& p, bool narrow, int bn, int flavor,
     (void)flavor;
     if (!narrow) {
         switch (bn) {
-            case 128: return launch_cfg<T, 8, 16, 1, 128, 0>(p, st);
-            case 96: return launch_cfg<T, 8, 16, 1, 96, 0>(p, st);
-            default: return launch_cfg<T, 8, 16, 1, 64, 0>(p, st);
+            case 128: return launch_cfg<T, 8, 16, 1, 128>(p, st);
+            case 96: return launch_cfg<T, 8, 16, 1, 96>(p, st);
+            default: return launch_cfg<T, 8, 16, 1, 64>(p, st);
         }
     }
     switch (bn) {
-        case 128: return launch_cfg<T, 8, 8, 2, 128, 0>(p, st);
-        case 96: return launch_cfg<T, 8, 8, 2, 96, 0>(p, st);
-        default: return launch_cfg<T, 8, 8, 2, 64, 0>(p, st);
+        case 128: return launch_cfg<T, 8, 8, 2, 128>(p, st);
+        case 96: return launch_cfg<T, 8, 8, 2, 96>(p, st);
+        default: return launch_cfg<T, 8, 8, 2, 64>(p, st);
     }
 }
 hipError_t launch_conv(const ConvParams& p, bool is_bf16, bool narrow, int bn, int flavor, hipStream_t st) {
