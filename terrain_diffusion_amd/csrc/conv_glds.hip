@@ -500,11 +500,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TD_T(tr_end);
     if (lane == 0) {
-        unsigned long long* tb = (unsigned long long*)p.partial + ((size_t)blockIdx.x * (WAVES_M * WAVES_N) + wave) * 8;
+        unsigned long long* tb = (unsigned long long*)p.partial + ((size_t)blockIdx.x * (WAVES_M * WAVES_N) + wave) * 16;  // 16 u64 per wave
         tb[0] = tr_pro - tr_start; tb[1] = tr_loop - tr_pro; tb[2] = tr_end - tr_loop; tb[3] = tr_wait; tb[4] = tr_stage; tb[5] = tr_start; tb[6] = tr_end;
-        tb[2] = tr_rt0; tb[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8) | __builtin_amdgcn_s_getreg((3 << 11) | 20);
-        tb[4] = __builtin_amdgcn_s_memrealtime();
-        tb[7] = tb[4] - tr_rt0;  // 100 MHz constant clock: shader clock = 100 MHz * (tb[6]-tb[5]) / tb[7]
+        tb[8] = tr_rt0; tb[9] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8) | __builtin_amdgcn_s_getreg((3 << 11) | 20);
+        tb[10] = __builtin_amdgcn_s_memrealtime();
+        tb[7] = tb[10] - tr_rt0;  // 100 MHz constant clock: shader clock = 100 MHz * (tb[6]-tb[5]) / tb[7]
     }
 #endif
 }

@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
     if (ksplit > 1) CK(hipMalloc(&partial, (size_t)ksplit * M * Cout * 4));
 #ifdef TD_TRACE
-    const size_t trace_n = (size_t)65536 * 8 * 8;
+    const size_t trace_n = (size_t)65536 * 12 * 16;
     CK(hipMalloc(&partial, trace_n * 8)); CK(hipMemset(partial, 0, trace_n * 8));
 #endif
     ConvParams p; memset(&p, 0, sizeof p);
@@ -54,21 +54,21 @@ int main(int argc, char** argv) {
            flop / ms / 1e9, flop / ms / 1e9 / 25.0, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * ksplit);
 #ifdef TD_TRACE
     {
-        const int wgs = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, nw = (flavor == 4 ? 12 : 8);
-        std::vector<unsigned long long> tb((size_t)wgs * nw * 8);
+        const int wgs = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, nw = flavor == 4 ? 12 : (flavor == 3 ? 4 : 8), TS = 16;  // waves per workgroup of the variant, u64 per wave record
+        std::vector<unsigned long long> tb((size_t)wgs * nw * TS);
         CK(hipMemcpy(tb.data(), partial, tb.size() * 8, hipMemcpyDeviceToHost));
         double s[5] = {0, 0, 0, 0, 0}; unsigned long long t0 = ~0ull, t1 = 0;
-        for (int i = 0; i < wgs * nw; ++i) { for (int j = 0; j < 5; ++j) s[j] += (double)tb[(size_t)i * 8 + j]; if (tb[(size_t)i*8+5] && tb[(size_t)i*8+5] < t0) t0 = tb[(size_t)i*8+5]; if (tb[(size_t)i*8+6] > t1) t1 = tb[(size_t)i*8+6]; }
+        for (int i = 0; i < wgs * nw; ++i) { for (int j = 0; j < 5; ++j) s[j] += (double)tb[(size_t)i * TS + j]; if (tb[(size_t)i*TS+5] && tb[(size_t)i*TS+5] < t0) t0 = tb[(size_t)i*TS+5]; if (tb[(size_t)i*TS+6] > t1) t1 = tb[(size_t)i*TS+6]; }
         {   // per-CU timeline from the 100 MHz realtime stamps of wave 0 of every workgroup: idle gap between consecutive workgroups
             std::vector<std::array<unsigned long long, 3>> ev;
-            for (int w = 0; w < wgs; ++w) { const unsigned long long* t = &tb[(size_t)w * nw * 8]; const unsigned long long id = t[3]; const unsigned long long cu = ((id >> 8) & 0xff00) >> 8 | (((id >> 8) >> 13) & 7) << 4 | (id & 15) << 8; ev.push_back({cu, t[2], t[4]}); }
+            for (int w = 0; w < wgs; ++w) { const unsigned long long* t = &tb[(size_t)w * nw * TS]; const unsigned long long id = t[9]; const unsigned long long cu = ((id >> 8) & 0xff00) >> 8 | (((id >> 8) >> 13) & 7) << 4 | (id & 15) << 8; ev.push_back({cu, t[8], t[10]}); }
             std::sort(ev.begin(), ev.end());
             double gap = 0, busy = 0; int ngap = 0, ncu = 0; unsigned long long first = ~0ull, last = 0, maxper = 0, cnt = 0;
             for (size_t i = 0; i < ev.size(); ++i) { busy += (double)(ev[i][2] - ev[i][1]); first = std::min(first, ev[i][1]); last = std::max(last, ev[i][2]);
                 if (i == 0 || ev[i][0] != ev[i-1][0]) { ++ncu; cnt = 1; } else { gap += (double)ev[i][1] - (double)ev[i-1][2]; ++ngap; ++cnt; } maxper = std::max(maxper, cnt); }
             printf("  timeline: %d distinct CUs, max %llu WGs on one CU, span %.1f us, mean WG %.2f us, mean idle gap between consecutive WGs on a CU %.2f us\n", ncu, maxper, (last - first) / 100.0, busy / wgs / 100.0, ngap ? gap / ngap / 100.0 : 0.0);
         }
-        double clk = 0; for (int i = 0; i < wgs * nw; ++i) clk += 100.0 * (double)(tb[(size_t)i*8+6] - tb[(size_t)i*8+5]) / (double)tb[(size_t)i*8+7];
+        double clk = 0; for (int i = 0; i < wgs * nw; ++i) clk += 100.0 * (double)(tb[(size_t)i*TS+6] - tb[(size_t)i*TS+5]) / (double)tb[(size_t)i*TS+7];
         printf("  shader clock during the kernel (s_memtime / s_memrealtime): %.0f MHz\n", clk / (wgs * nw));
         for (int j = 0; j < 5; ++j) s[j] /= (double)wgs * nw;
         printf("  trace (s_memtime ticks, mean per wave): prologue %.0f  loop %.0f (of which tap-entry wait %.0f, restage %.0f, body %.0f)  epilogue %.0f  | WG total %.0f | kernel span %.0f ticks = %.2f ticks/us\n",
