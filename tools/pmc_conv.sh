@@ -1,6 +1,6 @@
 # PMC passes over one conv_bench configuration; one rocprofv3 run per counter group, counters only (no traces)
 cd /tmp && export TMPDIR=/tmp
-BIN=${BIN:-$GRAFT_REPO_ROOT/tools/conv_bench_pipe.out}
+BIN=${BIN:-$GRAFT_REPO_ROOT/tools/conv_bench.out}
 ARGS=${ARGS:-"64 64 64 384 384 9 1 128 1 2 1"}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_conv
 rm -rf $OUT; mkdir -p $OUT
