@@ -72,7 +72,7 @@ __device__ __forceinline__ void frag_pixel(int q0, int l31, int& img, int& ty, i
 #endif
 
 template <int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && BN == 192) ? 1 : ((WAVES_M * WAVES_N + 3) / 4 < 2 ? 2 : (WAVES_M * WAVES_N + 3) / 4)) void conv_glds_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4 < 2 ? 2 : (WAVES_M * WAVES_N + 3) / 4) void conv_glds_kernel(const ConvParams p) {
     typedef __bf16 T;
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
     constexpr int TPIX = TH * TW, BM = NIMG * TPIX;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
     constexpr int PITCH = 144;
     constexpr int A_BASE = RING * B_BYTES, A_BYTES = NPATCH * PITCH;
     static_assert(WM % 32 == 0 && WN % 32 == 0, "tile shape");
-    static_assert((RING - 1) * B_BYTES + ((NT - 1) % 3) * 4096 + 128 < 65536 && 2 * PW * PITCH + 2 * PITCH + 128 < 65536, "ds_read offset field");
+    static_assert((RING - 1) * B_BYTES + (NT - 1) * 4096 + 128 < 65536 && 2 * PW * PITCH + 2 * PITCH + 128 < 65536, "ds_read offset field");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // the ONLY LDS object: its offset is 0
     unsigned char* s_a = smem + A_BASE;
@@ -235,9 +235,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wbase[ks] = (unsigned)(nl * 128 + (((ks * 2 + lh) ^ TD_SWZ(nl)) << 4));
     }
-    unsigned wbase3[4];  // second base for cout blocks 3..5 of a 192-wide wave tile (keeps the ds_read offset inside 16 bits)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) wbase3[ks] = wbase[ks] + 3 * 4096;
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -255,7 +252,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
     u32x4 wfA_[NT], xfA_[MT], wfB_[NT], xfB_[MT];
 #define TD_FRAG_READ(WF, XF, SLOT, KS, TOFF)                                                                 \
     {                                                                                                        \
-        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) WF[j_] = *(const u32x4*)(smem + (j_ < 3 ? wbase[KS] : wbase3[KS]) + ((SLOT) * B_BYTES + (j_ % 3) * 4096)); \
+        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) WF[j_] = *(const u32x4*)(smem + wbase[KS] + ((SLOT) * B_BYTES + j_ * 4096)); \
         _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_) XF[i_] = *(const u32x4*)(smem + xbase[i_] + ((TOFF) + (KS) * 32)); \
     }
 #define TD_FRAG_MFMA(WF, XF)                                                                                 \
@@ -543,7 +540,6 @@ static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
 //   1 "small" : 4 waves, 128-pixel tile (8x16, narrow maps 8x8 x 2 images), bn 128 -> waves 2x2 (64 px x 64 co), bn 96 -> 4x1 (32 px x 96 co);
 //               ~71 KB LDS -> two independent workgroups per CU whose prologues / epilogues / barrier stalls overlap
 hipError_t launch_conv_glds(const ConvParams& p, bool narrow, int bn, int variant, hipStream_t st) {
-    if (!narrow && bn == 192 && variant == 4) return launch_glds_cfg<16, 16, 1, 192, 4, 1>(p, st);  // 4 fat waves (one per SIMD, 64 px x 192 couts each)
     if (!narrow && bn == 192 && variant == 2) return launch_glds_cfg<16, 16, 1, 192, 4, 3>(p, st);
     if (variant == 1) {
         if (!narrow) return bn == 128 ? launch_glds_cfg<8, 16, 1, 128, 2, 2>(p, st) : launch_glds_cfg<8, 16, 1, 96, 4, 1>(p, st);

@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
     ConvParams p; memset(&p, 0, sizeof p);
     p.nseg = 1; p.seg[0].src = x; p.seg[0].C = Cin; p.seg[0].cstride = Cin; p.seg[0].Hs = H; p.seg[0].Ws = W; p.seg[0].taps = taps; p.seg[0].xform = xform; p.seg[0].scale = 1.f;
     p.wpack = w; p.N = N; p.H = H; p.W = W; p.Cout = Cout; p.CoutPad = Cout; p.kgroups = kgroups; p.ksplit = ksplit; p.partial = partial;
-    bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4) ? 4 : 2) : 1; int TH = ((flavor == 2 || flavor == 4 || flavor == 6) && !narrow) ? 16 : 8;
+    bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4) ? 4 : 2) : 1; int TH = ((flavor == 2 || flavor == 4) && !narrow) ? 16 : 8;
     p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH; p.img_groups = (N + NIMG - 1) / NIMG; p.n_ntiles = Cout / bn;
     p.epi = epi; p.out = out; p.out_cstride = Cout;
     if (epi == EPI_EMB_SILU) { float* cv; CK(hipMalloc(&cv, (size_t)N * Cout * 4)); std::vector<float> hc((size_t)N * Cout, 1.01f); CK(hipMemcpy(cv, hc.data(), hc.size() * 4, hipMemcpyHostToDevice)); p.cvec = cv; p.cvec_stride = Cout; }
@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
            flop / ms / 1e9, flop / ms / 1e9 / 25.0, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * ksplit);
 #ifdef TD_TRACE
     {
-        const int wgs = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, nw = flavor == 4 ? 12 : ((flavor == 3 || flavor == 6) ? 4 : 8), TS = 16;  // waves per workgroup of the variant, u64 per wave record
+        const int wgs = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, nw = flavor == 4 ? 12 : (flavor == 3 ? 4 : 8), TS = 16;  // waves per workgroup of the variant, u64 per wave record
         std::vector<unsigned long long> tb((size_t)wgs * nw * TS);
         CK(hipMemcpy(tb.data(), partial, tb.size() * 8, hipMemcpyDeviceToHost));
         double s[5] = {0, 0, 0, 0, 0}; unsigned long long t0 = ~0ull, t1 = 0;
