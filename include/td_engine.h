@@ -62,7 +62,8 @@ void td_engine_destroy(td_engine* e);
 int td_engine_synchronize(td_engine* e);
 /* raw hipStream_t the engine launches on (for timing with HIP events on the right stream) */
 void* td_engine_stream(td_engine* e);
-/* tuning knobs, e.g. "splitk"=0/1, "graph"=0/1, "bn128_min_wgs"=N */
+/* knobs: "graph"=0/1, "splitk"=0/1, "batch_invariant"=0/1, "solver_order"=1/2 (EDMDPMSolverMultistepScheduler.config.solver_order),
+ * "glds_variant"=-1/0/1 and "glds_bn"=0/96/128 (force the conv tile shape: test hook), "plan_cache_mb", "plan_cache_max", "profile"=0/1 */
 int td_engine_set_option(td_engine* e, const char* key, int64_t value);
 
 /* With option "profile"=1 the samplers run eagerly (no graph) with HIP events recorded on the engine stream around every
@@ -106,8 +107,10 @@ int td_standard_normal(td_engine* e, uint64_t seed, int64_t n, float* out);     
 int td_noise_patches(td_engine* e, uint64_t base_seed, int n_windows, const int64_t* origins_host, int h, int w,
                      int channels, int tile_h, int tile_w, float scale, float* out);
 
-/* ---- schedule (terrain_diffusion/scheduler/dpmsolver.py:285-342) — host ------------------------------------ */
-int td_schedule_karras(int n, float sigma_min, float sigma_max, float rho, float* sigmas_out /*n+1*/, float* timesteps_out /*n*/);
+/* ---- schedule (terrain_diffusion/scheduler/dpmsolver.py:285-342): NOT exported.  The Karras sigma ladder is a few dozen fp32 scalars that
+ * the reference computes with torch CPU ops; the host scheduler (terrain_diffusion_amd/scheduler.py) repeats those ops and is bit-exact.
+ * A C restatement with libm powf differs in the last bits (2e-6), so round 1's td_schedule_karras was removed rather than ship an
+ * export that disagrees with the product path.  The samplers below take the sigma ladder from the caller. */
 
 /* ---- samplers ---------------------------------------------------------------------------------------------
  * Inner loop of sample_base_diffusion (terrain_diffusion/training/evaluation/sample_diffusion_base.py:147-162)

@@ -47,7 +47,6 @@ _SIGS = {
     "td_tile_seed": (C.c_uint64, [C.c_uint64, C.c_int64, C.c_int64]),
     "td_standard_normal": (C.c_int, [_P, C.c_uint64, C.c_int64, _P]),
     "td_noise_patches": (C.c_int, [_P, C.c_uint64, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
-    "td_schedule_karras": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_float, _P, _P]),
     "td_sample_edm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, _P]),
     "td_sample_consistency": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P]),
     "td_sample_edm_img": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, _P, C.c_int, _P]),

@@ -12,56 +12,9 @@
 //     taps (mid-tap barrier, next tap's first fragments requested behind the current MFMAs);
 //   * bf16 results leave as dwordx4 stores after v_permlane32_swap pairs; optional pre-activated second output; split-K.
 // DESIGN.md §4 has the measurements behind each of these choices and the list of variants that were tried and dropped.
-#include "td_device.h"
+#include "conv_common.h"
 
 namespace td {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// one 1-KiB LDS-DMA piece per wave: lane l copies 16 bytes from (uniform base + its own 32-bit offset) to LDS[lds_base + imm + 16*l].
-// M0 is written in the statement that uses it (it is compiler-reserved and not preserved between statements).
-#define TD_GLDS16(VOFF, SBASE, LDS_BASE, IMM)                                                                 \
-    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                          \
-                 ::"v"(VOFF), "s"(SBASE), "s"(LDS_BASE), "n"(IMM) : "memory", "scc")
-
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-// v_permlane32_swap: lanes 32-63 of a exchange with lanes 0-31 of b (both halves of a wave take part)
-__device__ __forceinline__ void swap_halves(unsigned& a, unsigned& b) {
-    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-    a = r[0]; b = r[1];
-}
-
-// Pixel owned by lane (l31) of the 32-pixel MFMA fragment that starts at tile-linear pixel q0 (a multiple of 32).
-// ds_read_b128 is serviced in four fixed 16-lane groups, {0-3,12-15,20-27} and {4-11,16-19,28-31} for the lower half-wave (guide
-// §LDS); with 128-byte rows swizzled by ((row >> 1) & 7) a group is conflict-free iff its 16 rows are distinct mod 16.  On a
-// 16-wide tile each group therefore takes one whole tile row (16 consecutive patch rows, for every tap shift); the natural
-// "lane = pixel" order would mix two tile rows 18 patch rows apart inside a group and cost 2 LDS cycles per group instead of 1.
-template <int TW, int TPIX>
-__device__ __forceinline__ void frag_pixel(int q0, int l31, int& img, int& ty, int& tx) {
-#ifndef TD_NO_REMAP
-#define TD_REMAP_ON 1
-#else
-#define TD_REMAP_ON 0
-#endif
-    if constexpr (TW == 16 && TD_REMAP_ON) {
-        const bool g2 = (l31 >= 4 && l31 < 12) || (l31 >= 16 && l31 < 20) || l31 >= 28;
-        const int u = g2 ? (l31 < 12 ? l31 - 4 : (l31 < 20 ? l31 - 8 : l31 - 16)) : (l31 < 4 ? l31 : (l31 < 16 ? l31 - 8 : l31 - 12));
-        img = q0 / TPIX;
-        ty = (q0 % TPIX) / 16 + (g2 ? 1 : 0);
-        tx = u;
-    } else if constexpr (TW == 8 && TD_REMAP_ON) {
-        // 8-wide tile, patch rows 12 pixels apart: the fragment is 4 tile rows x 8; group one takes the LEFT halves of the four rows
-        // (patch rows p, p+12, p+24, p+36 (+0..3): residues p+{0..3}, p+{12..15}, p+{8..11}, p+{4..7} mod 16), group two the right halves
-        const bool g2 = (l31 >= 4 && l31 < 12) || (l31 >= 16 && l31 < 20) || l31 >= 28;
-        const int u = g2 ? (l31 < 12 ? l31 - 4 : (l31 < 20 ? l31 - 8 : l31 - 16)) : (l31 < 4 ? l31 : (l31 < 16 ? l31 - 8 : l31 - 12));
-        img = q0 / TPIX;
-        ty = (q0 % TPIX) / 8 + (u >> 2);
-        tx = (u & 3) + (g2 ? 4 : 0);
-    } else {
-        const int q = q0 + l31, r = q % TPIX;
-        img = q / TPIX; ty = r / TW; tx = r % TW;
-    }
-}
 
 #ifdef TD_TRACE  // in-kernel phase timing with s_memtime (tools/conv_bench.hip only): per wave, cycles spent per phase
 #define TD_T(v) unsigned long long v = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -109,7 +62,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
     const unsigned long long tr_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
+    // XCD-aware order (workgroup b runs on XCD b % 8; only speed depends on it): XCD x takes the contiguous range [x*G/8, (x+1)*G/8) of
+    // logical ids, so the n_ntiles cout-tile siblings of a pixel tile (consecutive logical ids) run on ONE XCD at about the same time and
+    // share its L2 copy of the halo patch instead of fetching it from HBM once per sibling.
     int bid = blockIdx.x;
+#ifndef TD_NO_XCD_REMAP
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+#endif
     const int ntile = bid % p.n_ntiles; bid /= p.n_ntiles;
     const int mtiles = p.tiles_x * p.tiles_y * p.img_groups;
     const int mtile = bid % mtiles;
@@ -385,7 +344,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
                 for (int r = 0; r < 16; ++r) t_ += acc[i][j][r];
         if (t_ == 12345.678f) ((float*)p.out)[tid] = t_;
     }
-    if (p.N < 0)
+    if (p.N >= 0) return;
 #endif
     // Wide path (bf16 output, Cout % 8 == 0): the C layout gives a lane 4 consecutive couts (8 B) per row group and its partner
     // lane (l ^ 32) the next 4; one v_permlane32_swap per dword turns two row groups into one 16-byte run per lane, so the tile
@@ -518,11 +477,13 @@ static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
     for (int s = 0; s < p.nseg; ++s) { if (p.seg[s].taps == 9 && seen1) return hipErrorInvalidValue; if (p.seg[s].taps != 9) seen1 = true; }
     const int grid = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * p.ksplit;
     auto kern = conv_glds_kernel<TH, TW, NIMG, BN, WAVES_M, WAVES_N>;
-    static bool attr_set = false;  // one per instantiation
-    if (!attr_set) {
+    // per (instantiation, device): hipFuncSetAttribute applies to the CURRENT device's copy of the kernel only
+    static bool attr_set[64] = {};
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES_M * WAVES_N), lds, st, p);
     hipError_t e = hipGetLastError();

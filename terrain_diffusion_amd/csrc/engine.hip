@@ -17,6 +17,7 @@
 // single translation unit: kernels are compiled together with the host runtime
 #include "conv_igemm.hip"
 #include "conv_glds.hip"
+#include "conv_pp.hip"
 #include "small_kernels.hip"
 
 using namespace td;
@@ -37,6 +38,15 @@ static inline uint16_t f2bf(float f) {  // round-to-nearest-even, NaN-preserving
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
+
+// Every C-ABI entry point runs on its engine's device and leaves the caller's current device as it found it.
+struct DevGuard {
+    int prev = -1, cur = -1;
+    explicit DevGuard(int dev) : cur(dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); }
+    ~DevGuard() { if (prev >= 0 && prev != cur) (void)hipSetDevice(prev); }
+    DevGuard(const DevGuard&) = delete;
+    DevGuard& operator=(const DevGuard&) = delete;
+};
 
 struct DevBuf {
     void* p = nullptr;
@@ -65,6 +75,8 @@ static bool is_device_ptr(const void* p) {
 
 struct td_engine {
     int device = 0;
+    int n_cus = 256;
+    void* zeros = nullptr;     // 4 KiB of zeros: halo source of the LDS-DMA patch staging (conv_pp.hip)
     hipStream_t stream = nullptr;
     std::map<std::string, int64_t> opt;
     // scratch for I/O staging
@@ -155,7 +167,8 @@ struct Op {
     bool narrow = false;
     int bn = 64;
     int glds_variant = 0;      // 0: 8 waves x 256 pixels, 1: 4 waves x 128 pixels
-    int flavor = 0;            // 0: per-tap register-staged kernel (conv_igemm.hip); 2: LDS-DMA throughput kernel (conv_glds.hip)
+    int flavor = 0;            // 0: per-tap register-staged kernel (conv_igemm.hip); 2: LDS-DMA throughput kernel (conv_glds.hip);
+                               // 3: persistent ping-pong kernel (conv_pp.hip)
     int cvec_off = -1;         // EPI_EMB_SILU: offset of this block's c vector
     int out_C = 0, out_H = 0, out_W = 0;  // output tensor geometry (debug read-back)
     // ATTN
@@ -177,7 +190,11 @@ struct Plan {
     hipGraphExec_t graph = nullptr;
     std::vector<float> graph_sigmas;
     float graph_sigma_data = 0.f;
-    ~Plan() { if (graph) (void)hipGraphExecDestroy(graph); }
+    int graph_solver_order = 0;
+    size_t bytes = 0;          // device memory owned by this plan (activations, partials, sampler state)
+    uint64_t last_use = 0;     // LRU stamp (td_unet::use_clock)
+    void drop_graph() { if (graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; } }
+    ~Plan() { drop_graph(); }
 };
 
 struct td_unet {
@@ -200,6 +217,7 @@ struct td_unet {
     int cond_row_len = 0;
     int n_blocks = 0;
     std::map<std::string, std::unique_ptr<Plan>> plans;
+    uint64_t use_clock = 0;
     size_t esize() const { return bf16 ? 2 : 4; }
 };
 
@@ -349,7 +367,6 @@ static const float kMixNew = 0.3f / 0.76157731058639082f;
 
 static int finalize(td_unet* u) {
     for (auto& p : u->params) if (!p.set) return fail(TD_ERR_STATE, "parameter not set: " + p.name);
-    HIP_TRY(hipSetDevice(u->eng->device));
     const int chunk = u->chunk;
     auto folded = [&](const std::string& n, float gain) -> const std::vector<float>* {
         auto& v = u->folded[n];
@@ -473,6 +490,7 @@ static int new_buf(Plan& pl, size_t bytes, void** out) {
     Buf b(new DevBuf());
     HIP_TRY(b->alloc(bytes, true));
     *out = b->p;
+    pl.bytes += b->bytes;
     pl.bufs.push_back(std::move(b));
     return TD_OK;
 }
@@ -480,15 +498,30 @@ static int new_buf(Plan& pl, size_t bytes, void** out) {
 struct SegSpec { const Tensor* t; int C; int taps; int resample; int xform; float scale; };
 
 static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
-    char key[64];
-    snprintf(key, sizeof key, "%d_%d_%d_%d%d%d_%lld", N, H, W, (int)u->eng->option("batch_invariant", 0), (int)u->eng->option("glds", 1),
-             (int)u->eng->option("splitk", 1) + 2 * (int)u->eng->option("producer_act", 1), (long long)u->eng->option("glds_min_wgs", 8));
+    char key[96];
+    snprintf(key, sizeof key, "%d_%d_%d_%d%d%d_%lld_%d_%d", N, H, W, (int)u->eng->option("batch_invariant", 0), (int)u->eng->option("glds", 1),
+             (int)u->eng->option("splitk", 1) + 2 * (int)u->eng->option("producer_act", 1), (long long)u->eng->option("glds_min_wgs", 8),
+             (int)u->eng->option("glds_variant", -1), (int)u->eng->option("glds_bn", 0) + 1000 * (int)u->eng->option("pp", 0) + 10000 * (int)u->eng->option("pp_min_items_per_cu", 2));
     auto it = u->plans.find(key);
-    if (it != u->plans.end()) { *out = it->second.get(); return TD_OK; }
+    if (it != u->plans.end()) { it->second->last_use = ++u->use_clock; *out = it->second.get(); return TD_OK; }
     if (N < 1 || N > 1023 || H > 1023 || W > 1023) return fail(TD_ERR_ARG, "batch/size out of range");
     const int down = 1 << (u->cfg.n_levels - 1);
     if (H % down || W % down) return fail(TD_ERR_ARG, "H and W must be divisible by 2^(levels-1)");
-    HIP_TRY(hipSetDevice(u->eng->device));
+    // plan cache: least-recently-used plans are dropped once the cached plans exceed the byte budget (each owns a full activation set;
+    // InfiniteTensor batches vary in size, so an unbounded cache would pin one activation set per batch size ever seen)
+    {
+        const size_t budget = (size_t)u->eng->option("plan_cache_mb", 65536) << 20;
+        const size_t max_plans = (size_t)u->eng->option("plan_cache_max", 12);
+        size_t total = 0;
+        for (auto& kv : u->plans) total += kv.second->bytes;
+        while (!u->plans.empty() && (total > budget || u->plans.size() >= max_plans)) {
+            auto victim = u->plans.begin();
+            for (auto jt = u->plans.begin(); jt != u->plans.end(); ++jt) if (jt->second->last_use < victim->second->last_use) victim = jt;
+            HIP_TRY(hipStreamSynchronize(u->eng->stream));
+            total -= victim->second->bytes;
+            u->plans.erase(victim);
+        }
+    }
     std::unique_ptr<Plan> plp(new Plan());
     Plan& pl = *plp;
     pl.N = N; pl.H = H; pl.W = W;
@@ -527,6 +560,9 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
             const SegSpec& s = segs[i];
             ConvSeg& d = p.seg[i];
             d.src = s.t->ptr; d.C = (s.C + chunk - 1) / chunk * chunk; d.cstride = s.t->cstride; d.Hs = s.t->H; d.Ws = s.t->W;
+            // the kernels address activations with 32-bit element offsets (pixel * channel stride): refuse instead of wrapping around
+            if ((size_t)N * d.Hs * d.Ws * (size_t)d.cstride >= ((size_t)1 << 31))
+                return fail(TD_ERR_ARG, "batch too large for 32-bit activation addressing (N*H*W*C >= 2^31 elements in " + label + "): split the batch");
             d.taps = s.taps; d.resample = s.resample; d.xform = s.xform; d.scale = s.scale;
             if (s.xform == 2) {
                 if (!s.t->sumsq) return fail(TD_ERR_STATE, "pixel-norm source without sumsq: " + label);
@@ -551,6 +587,11 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
             const int64_t mt_big = tiles(op.narrow ? 8 : 16, op.narrow ? 4 : 1), mt_small = tiles(8, op.narrow ? 2 : 1);
             int variant = 0, bn2 = pick_bn(mt_big);
             if (bn2 && mt_big * (cw.cout_pad / bn2) < 1024) { variant = 1; bn2 = pick_bn(mt_small); }
+            // test hooks: "glds_variant" = 0 (big) / 1 (small) and "glds_bn" = 96 / 128 force the tile shape wherever it is legal
+            // (tests assert that every legal shape gives bit-identical results: same K order, same MFMA)
+            const int64_t fv = u->eng->option("glds_variant", -1), fbn = u->eng->option("glds_bn", 0);
+            if (bn2 && (fv == 0 || fv == 1)) { variant = (int)fv; bn2 = pick_bn(variant ? mt_small : mt_big); }
+            if (bn2 && ((fbn == 128 && c128) || (fbn == 96 && c96))) bn2 = (int)fbn;
             const int64_t mt2 = variant ? mt_small : mt_big;
             // "batch_invariant": kernel flavour and K order do not depend on the batch size (no split-K, LDS-DMA flavour whenever it
             // applies), so a window's result is bit-identical whatever other windows share its batch / GPU.
@@ -565,6 +606,17 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
                 const int64_t wgs = mt2 * p.n_ntiles, slots = variant ? 512 : 256;
                 if (!inv && use_splitk && u->eng->option("glds_splitk", 1) && kgroups >= 4 && wgs * 2 <= slots)
                     p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(u->eng->option("glds_splitk_max", 32), kgroups / std::max<int64_t>(1, u->eng->option("glds_splitk_min_groups", 1))), slots / wgs);
+                // persistent ping-pong flavour (conv_pp.hip): 3x3-only convs on >= 16-wide maps whose work items fill the chip at least
+                // "pp_min_items_per_cu" times; bit-identical to the LDS-DMA flavour (same K order, same MFMA), so the choice may depend on the batch
+                bool all9 = true;
+                for (int i = 0; i < p.nseg; ++i) all9 = all9 && p.seg[i].taps == 9;
+                const int64_t pp_items = tiles(16, 1) * (cw.cout_pad / bn2);
+                const int64_t pp_mode = u->eng->option("pp", 0);  // 0 off (default: measured on par with the LDS-DMA flavour), 1 auto, 2 wherever legal
+                if (pp_mode && all9 && !op.narrow && !out_f32 && cw.cout % 8 == 0 && p.ksplit == 1 &&
+                    (pp_mode == 2 || pp_items >= u->eng->option("pp_min_items_per_cu", 2) * (int64_t)u->eng->n_cus)) {
+                    op.flavor = 3; op.glds_variant = 0;
+                    p.tiles_x = (w + 15) / 16; p.tiles_y = (h + 15) / 16; p.img_groups = N;
+                }
             }
         }
         if (op.flavor == 0) {
@@ -579,13 +631,15 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
             p.ksplit = 1;
             if (use_splitk && !u->eng->option("batch_invariant", 0) && base < splitk_target / 2 && kgroups > 1) p.ksplit = (int)std::min<int64_t>(kgroups, (splitk_target + base - 1) / base);
         }
-        p.epi = epi; p.out_f32 = out_f32 ? 1 : 0; p.clip = clip;
+        p.epi = epi; p.out_f32 = out_f32 ? 1 : 0; p.clip = clip; p.zeros = u->eng->zeros;
         const int out_parts = p.ksplit > 1 ? (cw.cout_pad + 255) / 256 : p.n_ntiles * 2;
         if (out_f32) {
             outT->C = cw.cout; outT->cstride = 8; outT->H = h; outT->W = w; outT->sumsq = nullptr;
             if ((rc = new_buf(pl, (size_t)N * h * w * 8 * 4, &outT->ptr))) return rc;
         } else if ((rc = new_tensor(cw.cout, h, w, want_sumsq, out_parts, outT))) return rc;
         p.out = outT->ptr; p.out_cstride = outT->cstride; p.out_sumsq = outT->sumsq;
+        if ((size_t)N * h * w * (size_t)std::max(outT->cstride, cw.cout_pad) >= ((size_t)1 << 31))
+            return fail(TD_ERR_ARG, "batch too large for 32-bit activation addressing (output of " + label + "): split the batch");
         op.cvec_off = cvec_off; p.cvec_stride = u->c_total;
         if (res) {
             p.res = res->ptr; p.res_cstride = res->cstride; p.res_Hs = res->H; p.res_Ws = res->W; p.res_resample = res_resample;
@@ -715,6 +769,8 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
     HIP_TRY(pl.x->alloc(xbytes)); HIP_TRY(pl.m1->alloc(xbytes)); HIP_TRY(pl.xt->alloc(xbytes));
     HIP_TRY(pl.cond->alloc((size_t)N * std::max(1, u->cond_row_len) * 4));
     HIP_TRY(hipDeviceSynchronize());  // buffer memsets ran on the null stream; the engine stream is non-blocking
+    pl.bytes += 3 * xbytes;
+    pl.last_use = ++u->use_clock;
     *out = plp.get();
     u->plans[key] = std::move(plp);
     return TD_OK;
@@ -725,6 +781,9 @@ static int compute_cvecs(td_unet* u, Plan& pl, const std::vector<float>& t_steps
     hipStream_t st = u->eng->stream;
     const int rows = (int)t_steps.size() * pl.N;
     if (!pl.emb || pl.cvec_rows < rows) {
+        // a captured EDM graph holds raw pointers into cvec (run_unet's cbase): it dies with the buffers it points into
+        pl.drop_graph();
+        HIP_TRY(hipStreamSynchronize(st));
         pl.emb.reset(new DevBuf()); pl.cvec.reset(new DevBuf()); pl.tsteps.reset(new DevBuf());
         HIP_TRY(pl.emb->alloc((size_t)rows * u->emb_ch * 4));
         HIP_TRY(pl.cvec->alloc((size_t)rows * u->c_total * 4));
@@ -785,10 +844,11 @@ static int run_unet(td_unet* u, Plan& pl, int step) {
         ConvParams p = op.p;
         if (op.cvec_off >= 0) p.cvec = cbase + op.cvec_off;
         mark();
-        hipError_t e = op.flavor == 2 ? launch_conv_glds(p, op.narrow, op.bn, op.glds_variant, st) : launch_conv(p, u->bf16, op.narrow, op.bn, 0, st);
-        mark(); if (prof) { ev_kind.push_back(0); char tag[96]; snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 2 ? (op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit); ev_label.push_back(op.label + tag);
+        hipError_t e = op.flavor == 3 ? launch_conv_pp(p, op.bn, u->eng->n_cus, st)
+                       : op.flavor == 2 ? launch_conv_glds(p, op.narrow, op.bn, op.glds_variant, st) : launch_conv(p, u->bf16, op.narrow, op.bn, 0, st);
+        mark(); if (prof) { ev_kind.push_back(0); char tag[96]; snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 3 ? "p" : op.flavor == 2 ? (op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit); ev_label.push_back(op.label + tag);
             double kk = 0; for (int s_ = 0; s_ < p.nseg; ++s_) kk += (double)p.seg[s_].C * p.seg[s_].taps;
-            ev_flop.push_back(op.flavor == 2 ? 2.0 * p.N * p.H * p.W * (double)p.Cout * kk : 0.0); }
+            ev_flop.push_back(op.flavor >= 2 ? 2.0 * p.N * p.H * p.W * (double)p.Cout * kk : 0.0); }
         if (e != hipSuccess) return fail(TD_ERR_HIP, "conv launch " + op.label + ": " + hipGetErrorString(e));
     }
     return TD_OK;
@@ -807,20 +867,27 @@ int td_engine_create(int device_id, td_engine** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(TD_ERR_HIP, "no HIP device visible: the engine has no CPU fallback");
     if (device_id < 0 || device_id >= ndev) return fail(TD_ERR_ARG, "bad device id");
-    HIP_TRY(hipSetDevice(device_id));
+    DevGuard dg_(device_id);
     td_engine* e = new td_engine();
     e->device = device_id;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) e->n_cus = prop.multiProcessorCount; }
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-    if (err != hipSuccess) { delete e; return fail(TD_ERR_HIP, hipGetErrorString(err)); }
+    if (err == hipSuccess) err = hipMalloc(&e->zeros, 4096);
+    if (err == hipSuccess) err = hipMemset(e->zeros, 0, 4096);
+    if (err == hipSuccess) err = hipDeviceSynchronize();
+    if (err != hipSuccess) { if (e->stream) (void)hipStreamDestroy(e->stream); delete e; return fail(TD_ERR_HIP, hipGetErrorString(err)); }
     *out = e;
     return TD_OK;
 }
 void td_engine_destroy(td_engine* e) {
     if (!e) return;
+    DevGuard dg_(e->device);
     if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->zeros) (void)hipFree(e->zeros);
     delete e;
 }
-int td_engine_synchronize(td_engine* e) { HIP_TRY(hipStreamSynchronize(e->stream)); return TD_OK; }
+int td_engine_synchronize(td_engine* e) {
+    DevGuard dg_(e->device); HIP_TRY(hipStreamSynchronize(e->stream)); return TD_OK; }
 void* td_engine_stream(td_engine* e) { return (void*)e->stream; }
 int td_engine_set_option(td_engine* e, const char* key, int64_t value) {
     if (!e || !key) return fail(TD_ERR_ARG, "null");
@@ -867,7 +934,7 @@ int td_unet_create(td_engine* e, const td_unet_config* cfg, int dtype, td_unet**
 }
 void td_unet_destroy(td_unet* u) {
     if (!u) return;
-    (void)hipSetDevice(u->eng->device);
+    DevGuard dg_(u->eng->device);
     (void)hipStreamSynchronize(u->eng->stream);
     delete u;
 }
@@ -894,6 +961,7 @@ int td_unet_set_prefolded(td_unet* u, int prefolded) {
     return TD_OK;
 }
 int td_unet_finalize(td_unet* u) {
+    DevGuard dg_(u->eng->device);
     if (u->finalized) return TD_OK;
     return finalize(u);
 }
@@ -901,6 +969,7 @@ int td_unet_finalize(td_unet* u) {
 int td_unet_cond_row_len(td_unet* u) { return u->cond_row_len; }
 
 int td_unet_forward(td_unet* u, int n, int H, int W, const float* x, const float* t_host, const float* cond, float* out) {
+    DevGuard dg_(u->eng->device);
     if (!u->finalized) return fail(TD_ERR_STATE, "finalize first");
     Plan* pl;
     int rc = build_plan(u, n, H, W, &pl);
@@ -942,6 +1011,7 @@ int td_unet_forward(td_unet* u, int n, int H, int W, const float* x, const float
 }
 
 int td_unet_read_activation(td_unet* u, int n, int H, int W, const char* label, float* out_host, int64_t capacity, int32_t dims[4]) {
+    DevGuard dg_(u->eng->device);
     Plan* pl;
     int rc = build_plan(u, n, H, W, &pl);
     if (rc) return rc;
@@ -991,21 +1061,9 @@ int td_unet_read_activation(td_unet* u, int n, int H, int W, const char* label, 
     return fail(TD_ERR_ARG, std::string("no conv op labelled ") + label);
 }
 
-// ---- schedule
-int td_schedule_karras(int n, float sigma_min, float sigma_max, float rho, float* sigmas_out, float* timesteps_out) {
-    if (n < 1) return fail(TD_ERR_ARG, "n");
-    const float mn = powf(sigma_min, 1.f / rho), mx = powf(sigma_max, 1.f / rho);
-    for (int i = 0; i < n; ++i) {
-        float ramp = n == 1 ? 0.f : (float)i / (float)(n - 1);
-        float s = powf(mx + ramp * (mn - mx), rho);
-        sigmas_out[i] = s;
-        if (timesteps_out) timesteps_out[i] = 0.25f * logf(s);
-    }
-    sigmas_out[n] = 0.f;
-    return TD_OK;
-}
-
-static void dpm_coefs(const float* sig, int n_steps, float sigma_data, std::vector<SchedCoef>& ks) {
+// ---- schedule: the Karras sigma ladder is computed by the host scheduler with the reference's own fp32 torch ops (bit-exact,
+// terrain_diffusion_amd/scheduler.py); the engine receives the sigmas and derives the per-step solver coefficients here.
+static void dpm_coefs(const float* sig, int n_steps, float sigma_data, int solver_order, std::vector<SchedCoef>& ks) {
     // fp32 scalar arithmetic in the reference's order (dpmsolver.py:245-258, 472-482, 515-540); order rule :688-715
     ks.resize(n_steps);
     int lower = 0;
@@ -1015,7 +1073,7 @@ static void dpm_coefs(const float* sig, int n_steps, float sigma_data, std::vect
         k.c_skip = (sd * sd) / (s * s + sd * sd);
         k.c_out = s * sd / sqrtf(s * s + sd * sd);
         const bool final = (i == n_steps - 1);
-        k.order = (lower < 1 || final) ? 1 : 2;
+        k.order = (solver_order < 2 || lower < 1 || final) ? 1 : 2;  // dpmsolver.py:688-715 (lower_order_final) with config.solver_order
         const float lam_t = 0.f - logf(st), lam_s = 0.f - logf(s);
         const float h = lam_t - lam_s;
         k.a = st / s;
@@ -1049,6 +1107,7 @@ static int stage_cond_img(td_unet* u, Plan& pl, int n, int HW, const float* cond
 
 int td_sample_edm_img(td_unet* u, int n, int H, int W, int n_steps, const float* sigmas_host, float sigma_data, const float* cond,
                       const float* cond_img, int cimg, float* x) {
+    DevGuard dg_(u->eng->device);
     if (!u->finalized) return fail(TD_ERR_STATE, "finalize first");
     if (n_steps < 1) return fail(TD_ERR_ARG, "n_steps");
     Plan* pl;
@@ -1071,7 +1130,9 @@ int td_sample_edm_img(td_unet* u, int n, int H, int W, int n_steps, const float*
     for (int i = 0; i < n_steps; ++i) ts[i] = atanf(sigmas_host[i] / sigma_data);  // trigflow_precondition_noise (dpmsolver.py:240-242)
     if ((rc = compute_cvecs(u, *pl, ts, (const float*)pl->cond->p))) return rc;
     std::vector<SchedCoef> ks;
-    dpm_coefs(sigmas_host, n_steps, sigma_data, ks);
+    const int solver_order = (int)e->option("solver_order", 2);
+    if (solver_order != 1 && solver_order != 2) return fail(TD_ERR_ARG, "solver_order must be 1 or 2");
+    dpm_coefs(sigmas_host, n_steps, sigma_data, solver_order, ks);
     const float c_in0 = 1.f / sqrtf(sigmas_host[0] * sigmas_host[0] + sigma_data * sigma_data);
 
     auto enqueue = [&]() -> int {
@@ -1090,8 +1151,8 @@ int td_sample_edm_img(td_unet* u, int n, int H, int W, int n_steps, const float*
     const bool use_graph = e->option("graph", 1) != 0 && e->option("profile", 0) == 0;
     if (use_graph) {
         std::vector<float> sg(sigmas_host, sigmas_host + n_steps + 1);
-        if (!pl->graph || pl->graph_sigmas != sg || pl->graph_sigma_data != sigma_data) {
-            if (pl->graph) { (void)hipGraphExecDestroy(pl->graph); pl->graph = nullptr; }
+        if (!pl->graph || pl->graph_sigmas != sg || pl->graph_sigma_data != sigma_data || pl->graph_solver_order != solver_order) {
+            pl->drop_graph();
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             rc = enqueue();
@@ -1101,7 +1162,7 @@ int td_sample_edm_img(td_unet* u, int n, int H, int W, int n_steps, const float*
             hipError_t ie = hipGraphInstantiate(&pl->graph, g, nullptr, nullptr, 0);
             (void)hipGraphDestroy(g);
             if (ie != hipSuccess) { pl->graph = nullptr; return fail(TD_ERR_HIP, std::string("graph instantiate: ") + hipGetErrorString(ie)); }
-            pl->graph_sigmas = sg; pl->graph_sigma_data = sigma_data;
+            pl->graph_sigmas = sg; pl->graph_sigma_data = sigma_data; pl->graph_solver_order = solver_order;
         }
         HIP_TRY(hipGraphLaunch(pl->graph, st));
     } else if ((rc = enqueue())) return rc;
@@ -1116,6 +1177,7 @@ int td_sample_edm(td_unet* u, int n, int H, int W, int n_steps, const float* sig
 
 int td_sample_consistency_img(td_unet* u, int n, int H, int W, float t, float sigma_data, const float* sample, const float* z, const float* cond,
                               const float* cond_img, int cimg, float* out) {
+    DevGuard dg_(u->eng->device);
     if (!u->finalized) return fail(TD_ERR_STATE, "finalize first");
     Plan* pl;
     int rc = build_plan(u, n, H, W, &pl);
@@ -1161,8 +1223,8 @@ uint64_t td_tile_seed(uint64_t base_seed, int64_t ty, int64_t tx) {
 }
 
 int td_standard_normal(td_engine* e, uint64_t seed, int64_t n, float* out) {
+    DevGuard dg_(e->device);
     if (n <= 0) return TD_OK;
-    HIP_TRY(hipSetDevice(e->device));
     std::vector<Buf> hold;
     OutStage os;
     int rc;
@@ -1181,9 +1243,9 @@ static inline int64_t fdiv(int64_t a, int64_t b) { int64_t q = a / b; return (a 
 
 int td_noise_patches(td_engine* e, uint64_t base_seed, int n_windows, const int64_t* origins, int h, int w, int channels, int tile_h, int tile_w,
                      float scale, float* out) {
+    DevGuard dg_(e->device);
     if (n_windows <= 0) return TD_OK;
     if (h > tile_h || w > tile_w) return fail(TD_ERR_UNSUPPORTED, "window larger than the noise tile");
-    HIP_TRY(hipSetDevice(e->device));
     // unique noise tiles touched by the windows
     std::map<std::pair<int64_t, int64_t>, int> slot;
     std::vector<uint64_t> seeds;
@@ -1239,6 +1301,7 @@ static void weight_window_host(int size, std::vector<float>& w) {
 }
 
 int td_linear_weight_window(td_engine* e, int size, float* out) {
+    DevGuard dg_(e->device);
     std::vector<float> w;
     weight_window_host(size, w);
     HIP_TRY(hipMemcpy(out, w.data(), w.size() * 4, is_device_ptr(out) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
@@ -1247,8 +1310,8 @@ int td_linear_weight_window(td_engine* e, int size, float* out) {
 
 int td_blend_windows(td_engine* e, float* canvas, int C, int Hc, int Wc, int size, int n_rows, const int32_t* row_starts, int n_cols,
                      const int32_t* col_starts, int n_tiles, const int32_t* wi, const int32_t* wj, const float* tiles, int accumulate) {
+    DevGuard dg_(e->device);
     if (C + 1 > 8) return fail(TD_ERR_UNSUPPORTED, "C+1 must be <= 8");
-    HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = e->stream;
     std::vector<int> rowmap((size_t)Hc * 4, -1), colmap((size_t)Wc * 4, -1), tile_of((size_t)n_rows * n_cols, -1);
     for (int ic = 0; ic < n_rows; ++ic)
@@ -1304,7 +1367,7 @@ int td_blend_windows(td_engine* e, float* canvas, int C, int Hc, int Wc, int siz
 }
 
 int td_blend_normalize(td_engine* e, const float* canvas, int C, int Hc, int Wc, float scale, float* out) {
-    HIP_TRY(hipSetDevice(e->device));
+    DevGuard dg_(e->device);
     std::vector<Buf> hold;
     const void* dc;
     int rc;

@@ -48,6 +48,7 @@ struct ConvParams {
     float* partial;       // split-K workspace [ksplit][N*H*W][CoutPad] fp32
     void* out2;           // optional second output, same layout as out: mp_silu(out2_scale * out) -- the consumer's activation, done once here
     float out2_scale;
+    const void* zeros;    // >= 16 zero bytes in device memory: source of the halo outside the image for LDS-DMA patch staging (conv_pp.hip)
 };
 
 struct SchedCoef {        // one DPM-Solver++ step, fp32 scalars computed on the host

@@ -1,52 +1,82 @@
-"""Host helpers of the annotated InfiniteDiffusion panorama (annotated_infinite_panorama.py:57-102), restated:
-1-D tiled deterministic noise (numpy SeedSequence -> PCG64DXSM, stays on the host by design: SURVEY.md a4), the 1-D linear blend
-kernel and the phase partition of a descending timestep list.  The SD-v1.5 U-Net/VAE of that script live in `diffusers` and are
-out of scope (parity unpinned); these helpers + infinite_tensor.py are the plumbing around a user-supplied denoiser."""
+"""Panorama-demo plumbing (BASELINE configs[0]): the host-side pieces around a user-supplied denoiser.
+
+Behavioural contract = annotated_infinite_panorama.py:57-102,145-150 (pinned bit-for-bit by tests/golden/geometry.npz); the
+implementation is this package's own: a column-addressed noise strip with a small tile cache, a closed-form 1-D tent window, and a
+bucketised phase split.  The SD-v1.5 U-Net / VAE of the demo live in `diffusers` (absent here: parity unpinned).
+The noise stays on the host by design (numpy's PCG64DXSM ziggurat stream is the definition of the field)."""
+from collections import OrderedDict
+
 import numpy as np
 import torch
 
+_U32 = 0xFFFFFFFF
+
+
+class NoiseStrip:
+    """Infinite (channels, height, +-inf) Gaussian strip cut into `tile`-column blocks.  Block b is the float32 ziggurat stream of
+    numpy's PCG64DXSM seeded with SeedSequence([seed, b mod 2^32]), so a column's values depend on (seed, column // tile) only and
+    any two requests agree where they overlap.  Recently used blocks are kept (overlapping windows re-read the same block)."""
+
+    def __init__(self, seed, channels=4, height=64, tile=256, keep=8):
+        self.seed, self.shape, self.tile, self.keep = int(seed), (int(channels), int(height), int(tile)), int(tile), int(keep)
+        self._blocks = OrderedDict()
+
+    def block(self, b):
+        hit = self._blocks.get(b)
+        if hit is None:
+            entropy = np.array([self.seed, b & _U32], dtype=np.uint32)
+            gen = np.random.Generator(np.random.PCG64DXSM(np.random.SeedSequence(entropy)))
+            hit = gen.standard_normal(self.shape, dtype=np.float32)
+            self._blocks[b] = hit
+            while len(self._blocks) > self.keep:
+                self._blocks.popitem(last=False)
+        else:
+            self._blocks.move_to_end(b)
+        return hit
+
+    def columns(self, x0, width):
+        """(channels, height, width) window starting at absolute column x0 (any sign)."""
+        pieces, x, end = [], int(x0), int(x0) + int(width)
+        while x < end:
+            b, inside = divmod(x, self.tile)          # floor semantics: negative columns land in negative blocks
+            take = min(self.tile - inside, end - x)
+            pieces.append(self.block(b)[:, :, inside:inside + take])
+            x += take
+        return np.ascontiguousarray(np.concatenate(pieces, axis=2)) if len(pieces) != 1 else np.array(pieces[0], dtype=np.float32, order="C")
+
 
 def tiled_gaussian_noise(seed, x0, width, channels=4, height=64, tile=256):
-    out = np.empty((channels, height, width), dtype=np.float32)
-    first_tx, last_tx = x0 // tile, (x0 + width - 1) // tile
-    for tx in range(first_tx, last_tx + 1):
-        tile_x0 = tx * tile
-        ox0, ox1 = max(x0, tile_x0), min(x0 + width, tile_x0 + tile)
-        ss = np.random.SeedSequence(np.array([seed, tx & 0xFFFFFFFF], dtype=np.uint32))
-        rng = np.random.Generator(np.random.PCG64DXSM(ss))
-        tile_noise = rng.standard_normal((channels, height, tile), dtype=np.float32)
-        out[:, :, ox0 - x0:ox1 - x0] = tile_noise[:, :, ox0 - tile_x0:ox1 - tile_x0]
-    return out
+    """Function form with the demo's signature: one window of the strip identified by (seed, channels, height, tile)."""
+    return NoiseStrip(seed, channels, height, tile, keep=2).columns(x0, width)
 
 
 def linear_kernel(height, width):
-    x = torch.arange(width, dtype=torch.float32)
-    mid = (width - 1) / 2
-    w = 1 - 0.999 * torch.abs(x - mid) / mid
-    return w[None, :].expand(height, -1).contiguous()
+    """Horizontal tent window, constant over rows: 1 at the centre column, 1e-3 at the two edge columns (fp32, same operation order
+    as the demo so the blend weights are bit-identical)."""
+    centre = (width - 1) / 2
+    tent = torch.arange(width, dtype=torch.float32).sub_(centre).abs_().mul_(0.999).div_(centre).neg_().add_(1)
+    return tent.repeat(height, 1)
 
 
 def build_timestep_ranges(all_timesteps, thresholds):
-    thresholds = sorted(thresholds, reverse=True)
-    if not thresholds:
+    """Split a descending timestep vector into phases at the given thresholds: phase p holds the steps with exactly p thresholds
+    strictly above them (so phase 0 is t >= max threshold, the last phase t < min threshold); empty phases are dropped."""
+    cuts = sorted({int(t) for t in thresholds})
+    if not cuts:
         return [all_timesteps]
-    ranges, prev = [], None
-    for t in thresholds:
-        r = all_timesteps[all_timesteps >= t] if prev is None else all_timesteps[(all_timesteps >= t) & (all_timesteps < prev)]
-        if len(r) > 0:
-            ranges.append(r)
-        prev = t
-    tail = all_timesteps[all_timesteps < thresholds[-1]]
-    if len(tail) > 0:
-        ranges.append(tail)
-    return ranges
+    ts = torch.as_tensor(all_timesteps)
+    # number of cuts <= t, counted from the top: phase = len(cuts) - #{c : c <= t}
+    below_or_equal = torch.bucketize(ts, torch.tensor(cuts, dtype=ts.dtype), right=True)
+    phase = len(cuts) - below_or_equal
+    return [all_timesteps[phase == p] for p in range(len(cuts) + 1) if bool((phase == p).any())]
 
 
 def normalize(weighted, clamp=1e-6):
-    """annotated_infinite_panorama.py:145-146 (weight channel clamped at 1e-6)."""
+    """(C+1,...) weighted sums -> (C,...) values; the weight channel is clamped from below (annotated_infinite_panorama.py:145-146)."""
     return weighted[:-1] / weighted[-1:].clamp(min=clamp)
 
 
 def pack(values_chw, weight_hw):
-    """annotated_infinite_panorama.py:148-150."""
-    return torch.cat([values_chw * weight_hw[None], weight_hw[None]], dim=0)
+    """values (C,H,W), weight (H,W) -> (C+1,H,W) = [values * weight, weight] (annotated_infinite_panorama.py:148-150)."""
+    w = weight_hw[None]
+    return torch.cat([values_chw * w, w], dim=0)

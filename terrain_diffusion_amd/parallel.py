@@ -20,13 +20,7 @@ import torch
 import torch.distributed as dist
 
 
-def _tile_starts(length, tile_size, stride):
-    if length <= tile_size:
-        return [0]
-    starts = list(range(0, max(1, length - tile_size + 1), max(1, stride)))
-    if starts[-1] != length - tile_size:
-        starts.append(length - tile_size)
-    return starts
+from .geometry import tile_starts as _tile_starts  # noqa: E402
 
 
 def mesh_shape(world, n_rows, n_cols):

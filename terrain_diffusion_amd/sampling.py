@@ -17,13 +17,7 @@ from .engine import ptr, f32
 from . import noise as _noise
 
 
-def _tile_starts(length, tile_size, stride):
-    if length <= tile_size:
-        return [0]
-    starts = list(range(0, max(1, length - tile_size + 1), max(1, stride)))
-    if starts[-1] != length - tile_size:
-        starts.append(length - tile_size)
-    return starts
+from .geometry import tile_starts as _tile_starts  # noqa: E402  (reference name kept as an alias)
 
 
 def _linear_weight_window(size, device="cuda", dtype=torch.float32):

@@ -48,17 +48,6 @@ def test_tile_seed_host_function(golden):
         assert td._tile_seed(int(seed), int(ty), int(tx)) == int(ref)
 
 
-def test_schedule_host_function(golden):
-    import ctypes as C
-    from terrain_diffusion_amd._lib import lib
-    g = golden("schedule")
-    for n in (4, 12, 20, 32):
-        s = np.empty(n + 1, np.float32)
-        t = np.empty(n, np.float32)
-        assert lib().td_schedule_karras(n, 0.002, 80.0, 7.0, C.c_void_p(s.ctypes.data), C.c_void_p(t.ctypes.data)) == 0
-        assert np.allclose(s, g[f"sigmas_{n}"], rtol=2e-6, atol=0)
-
-
 def test_scheduler_mirror_matches_reference_trace(golden):
     """the Python EDMDPMSolverMultistepScheduler mirror (host maths, torch CPU) reproduces the reference's step() trace."""
     import terrain_diffusion_amd as td

@@ -10,6 +10,7 @@
 #include <array>
 #include "conv_igemm.hip"
 #include "conv_glds.hip"
+#include "conv_pp.hip"
 using namespace td;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 int main(int argc, char** argv) {
@@ -27,31 +28,61 @@ int main(int argc, char** argv) {
     for (auto& v : hw) v = 0x3c00 + (rand() & 0xff) + ((rand() & 1) << 15);          // small
     CK(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
     if (ksplit > 1) CK(hipMalloc(&partial, (size_t)ksplit * M * Cout * 4));
-#ifdef TD_TRACE
+#if defined(TD_TRACE) || defined(TD_PP_TRACE)
     const size_t trace_n = (size_t)65536 * 12 * 16;
     CK(hipMalloc(&partial, trace_n * 8)); CK(hipMemset(partial, 0, trace_n * 8));
 #endif
     ConvParams p; memset(&p, 0, sizeof p);
     p.nseg = 1; p.seg[0].src = x; p.seg[0].C = Cin; p.seg[0].cstride = Cin; p.seg[0].Hs = H; p.seg[0].Ws = W; p.seg[0].taps = taps; p.seg[0].xform = xform; p.seg[0].scale = 1.f;
     p.wpack = w; p.N = N; p.H = H; p.W = W; p.Cout = Cout; p.CoutPad = Cout; p.kgroups = kgroups; p.ksplit = ksplit; p.partial = partial;
-    bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4) ? 4 : 2) : 1; int TH = ((flavor == 2 || flavor == 4) && !narrow) ? 16 : 8;
+    bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4) ? 4 : 2) : 1; int TH = ((flavor == 2 || flavor == 4 || flavor == 5) && !narrow) ? 16 : 8;
     p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH; p.img_groups = (N + NIMG - 1) / NIMG; p.n_ntiles = Cout / bn;
     p.epi = epi; p.out = out; p.out_cstride = Cout;
+    { void* z; CK(hipMalloc(&z, 4096)); CK(hipMemset(z, 0, 4096)); p.zeros = z; }
     if (epi == EPI_EMB_SILU) { float* cv; CK(hipMalloc(&cv, (size_t)N * Cout * 4)); std::vector<float> hc((size_t)N * Cout, 1.01f); CK(hipMemcpy(cv, hc.data(), hc.size() * 4, hipMemcpyHostToDevice)); p.cvec = cv; p.cvec_stride = Cout; }
     if (epi == EPI_RESIDUAL) { void* r; float* ssq; CK(hipMalloc(&r, M * Cout * 2)); CK(hipMemcpy(r, hx.data(), std::min(hx.size(), M * Cout) * 2, hipMemcpyHostToDevice)); CK(hipMalloc(&ssq, M * 8 * 4)); CK(hipMemset(ssq, 0, M * 8 * 4));
         p.res = r; p.res_cstride = Cout; p.res_Hs = H; p.res_Ws = W; p.res_scale = 0.9f; p.clip = 256.f; p.out_sumsq = ssq; }
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) CK((flavor >= 2 ? launch_conv_glds(p, narrow, bn, flavor - 2, st) : launch_conv(p, true, narrow, bn, flavor, st)));
+    for (int i = 0; i < 3; ++i) CK((flavor == 5 ? launch_conv_pp(p, bn, 256, st) : flavor >= 2 ? launch_conv_glds(p, narrow, bn, flavor - 2, st) : launch_conv(p, true, narrow, bn, flavor, st)));
     CK(hipStreamSynchronize(st));
     const int reps = 20;
     CK(hipEventRecord(e0, st));
-    for (int i = 0; i < reps; ++i) CK((flavor >= 2 ? launch_conv_glds(p, narrow, bn, flavor - 2, st) : launch_conv(p, true, narrow, bn, flavor, st)));
+    for (int i = 0; i < reps; ++i) CK((flavor == 5 ? launch_conv_pp(p, bn, 256, st) : flavor >= 2 ? launch_conv_glds(p, narrow, bn, flavor - 2, st) : launch_conv(p, true, narrow, bn, flavor, st)));
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     double flop = 2.0 * M * Cout * Cin * taps;
     printf("N%d %dx%d Cin%d Cout%d taps%d xform%d bn%d ks%d fl%d epi%d : %.1f us  %.1f TFLOP/s (%.1f%% of 2500)  wgs=%d\n", N, H, W, Cin, Cout, taps, xform, bn, ksplit, flavor, epi, ms * 1e3,
            flop / ms / 1e9, flop / ms / 1e9 / 25.0, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * ksplit);
+    if (flavor == 5) {  // bit-exactness of the persistent ping-pong flavour against the LDS-DMA flavour (same K order, same MFMA)
+        std::vector<uint16_t> o5(M * Cout), o2(M * Cout);
+        CK(hipMemset(out, 0, M * Cout * 2));
+        CK(launch_conv_pp(p, bn, 256, st)); CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(o5.data(), out, o5.size() * 2, hipMemcpyDeviceToHost));
+        std::vector<float> s5, s2;
+        if (p.out_sumsq) { s5.resize(M * 8); CK(hipMemcpy(s5.data(), p.out_sumsq, s5.size() * 4, hipMemcpyDeviceToHost)); }
+        CK(hipMemset(out, 0, M * Cout * 2));
+        ConvParams q = p; q.tiles_y = (H + 15) / 16;
+        CK(launch_conv_glds(q, narrow, bn, 0, st)); CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(o2.data(), out, o2.size() * 2, hipMemcpyDeviceToHost));
+        if (p.out_sumsq) { s2.resize(M * 8); CK(hipMemcpy(s2.data(), p.out_sumsq, s2.size() * 4, hipMemcpyDeviceToHost)); }
+        size_t bad = 0, first = 0; for (size_t i = 0; i < o5.size(); ++i) if (o5[i] != o2[i]) { if (!bad) first = i; ++bad; }
+        size_t bads = 0; for (size_t i = 0; i < s5.size(); ++i) if (memcmp(&s5[i], &s2[i], 4)) ++bads;
+        size_t nz = 0; for (auto v : o2) nz += (v & 0x7fff) != 0;
+        printf("  check vs conv_glds: %zu / %zu outputs differ (first at %zu: pixel %zu cout %zu), sumsq diffs %zu, nonzero outputs %zu\n", bad, o5.size(), first, first / Cout, first % Cout, bads, nz);
+    }
+#ifdef TD_PP_TRACE
+    if (flavor == 5) {
+        std::vector<unsigned long long> tb((size_t)256 * 8 * 16);
+        CK(hipMemcpy(tb.data(), partial, tb.size() * 8, hipMemcpyDeviceToHost));
+        double s[7] = {0, 0, 0, 0, 0, 0, 0}, g[2][7] = {{0}};
+        for (int w = 0; w < 256 * 8; ++w) for (int j = 0; j < 7; ++j) { s[j] += (double)tb[(size_t)w * 16 + j]; g[(w & 7) >> 2][j] += (double)tb[(size_t)w * 16 + j]; }
+        const double nw = 256.0 * 8, tiles = (double)p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups / 256.0, taps = tiles * ksteps;
+        printf("  pp trace (shader cycles, mean per wave; %.1f tiles, %.0f taps per workgroup): total %.0f | epilogue %.0f (%.0f per tile)  load phase %.0f (%.0f/tap)  barrier-after-load %.0f (%.0f/tap)  mfma phase %.0f (%.0f/tap)  barrier-after-mfma %.0f (%.0f/tap) | clock %.0f MHz\n",
+               tiles, taps, s[5] / nw, s[0] / nw, s[0] / nw / tiles, s[1] / nw, s[1] / nw / taps, s[2] / nw, s[2] / nw / taps, s[3] / nw, s[3] / nw / taps, s[4] / nw, s[4] / nw / taps, 100.0 * s[5] / s[6]);
+        for (int q = 0; q < 2; ++q) printf("    group %d: epilogue %.0f  load %.0f/tap  bar1 %.0f/tap  mfma %.0f/tap  bar2 %.0f/tap\n", q, g[q][0] / (nw / 2) / tiles, g[q][1] / (nw / 2) / taps, g[q][2] / (nw / 2) / taps, g[q][3] / (nw / 2) / taps, g[q][4] / (nw / 2) / taps);
+    }
+#endif
 #ifdef TD_TRACE
     {
         const int wgs = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, nw = flavor == 4 ? 12 : (flavor == 3 ? 4 : 8), TS = 16;  // waves per workgroup of the variant, u64 per wave record
