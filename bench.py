@@ -1,25 +1,26 @@
 #!/usr/bin/env python
-"""Headline benchmark: decoded terrain megapixels / second at fixed steps (BASELINE.json).
+"""Headline benchmark: decoded terrain megapixels / second at fixed steps (BASELINE.json), terrain-diffusion-30m base model.
 
-    python bench.py --gpus N --steps K --warmup W [--workload tiles|grid8] [--tiles-per-step B] [--dtype bf16|fp32]
+    python bench.py --gpus N --steps K --warmup W [--workload grid8|grid32|tiles|cascade] [--dtype bf16|fp32]
 
-A "step" is one pass of the hot path over one batch of synthetic input:
-  tiles (default, BASELINE configs[1]): a batch of B (default 64) INDEPENDENT single 64x64-latent tiles of the
-        terrain-diffusion-30m base model, each through 20 EDM DPM-Solver++ steps, including noise generation, scheduler steps,
-        pack/normalise.  Independent tiles are batched through the U-Net exactly as the reference batches latent tiles
-        (latents_batch_size, world_pipeline.py:292,326-330).  B x 0.262144 decoded MP per step.  The single-tile (B=1) latency
-        is reported alongside as "latency_single_tile_ms".  N>1: every rank samples its own batch (independent objects -> weak).
-  grid32 (BASELINE configs[3]): ONE 32x32 tile grid (1056x1056 latent canvas, 71.37 decoded MP) sharded over the N ranks as a
-        2-D block mesh with a point-to-point seam exchange of window outputs over RCCL (terrain_diffusion_amd/parallel.py);
-        "scaling": "strong".
-  grid8 (BASELINE configs[2]): an 8x8 grid of overlapping tiles (stride 32) on a 288x288 latent canvas, 20 steps,
-        all 64 tiles batched per solver step, overlap blend at the end.  5.308416 decoded MP per step.
-Weights are synthetic (portable-RNG seeded, out_gain=1, emb_gain=0.5) and resident in HBM before the timed region; there
-is no network for checkpoints.  Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over one batch of synthetic input, inputs resident in HBM:
+  grid8  (default at N=1, BASELINE configs[2]): an 8x8 grid of overlapping 64x64-latent windows (stride 32) on a 288x288 latent
+         canvas, 20 EDM DPM-Solver++ steps, all 64 windows batched per solver step, overlap blend at the end: 5.308416 decoded MP.
+  grid32 (default at N>1, BASELINE configs[3]): ONE 32x32 window grid (1056x1056 latent canvas, 71.37 decoded MP) sharded over the N
+         ranks as a 2-D block mesh with the point-to-point seam exchange of window outputs over RCCL (terrain_diffusion_amd/parallel.py);
+         total work is fixed -> "scaling": "strong".  The line carries the seam bytes and the exchange time.
+  tiles  (BASELINE configs[1] batched): 64 INDEPENDENT single-tile jobs per step (no overlap): 16.78 decoded MP; N>1: every rank its own
+         batch (weak).  The literal configs[1] number (ONE tile, latency-bound) is reported on every N=1 line as "latency_single_tile_ms".
+  cascade (BASELINE configs[4] shapes on one GPU): coarse -> 2-phase latent -> decoder through the lazy InfiniteTensor graph with a capped
+         tile cache; see run_cascade().
+With --gpus N > 1 and no WORLD_SIZE in the environment bench.py launches its own N ranks (torch.distributed.run, 127.0.0.1).
+Weights are synthetic (portable-RNG seeded, out_gain=1, emb_gain=0.5): there is no network for checkpoints.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,26 +28,47 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GFLOP_PER_FORWARD = 193.654          # base model, one 64x64 tile (2 FLOP/MAC, convs+GEMMs+bmm)
-CONV_SHARE = 193.609 / 193.654       # share of those FLOPs issued by the conv_igemm kernel
 WEIGHT_BYTES_BF16 = 253_688_037 * 2  # algorithmic minimum HBM bytes per forward at batch 1 (weights once)
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+PROFILE_JSON = os.path.join(ROOT, "profiles", "r02_hbm_traffic_and_mfma_util.json")
+
+# terrain-diffusion-30m base model (configs/diffusion_base/30m/diffusion_192-3.cfg:54-68)
+BASE_CONFIG = dict(image_size=512, in_channels=5, out_channels=5, model_channels=192, model_channel_mults=[1, 2, 3, 4], layers_per_block=3,
+                   attn_resolutions=[8, 16], midblock_attention=True, concat_balance=0.5, conditional_inputs=[["tensor", 58, 1.0]], fourier_scale="pos")
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="tiles", choices=["tiles", "grid8", "grid32"])
+    ap.add_argument("--workload", default=None, choices=["grid8", "grid32", "tiles", "cascade"])
     ap.add_argument("--tiles-per-step", type=int, default=64)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"])
     ap.add_argument("--edm-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-tile latency leg (keeps rocprofv3 counter passes to the batched steps only)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start N ranks of this script on this node (one process per GPU, RCCL)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -55,7 +77,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    workload = args.workload or ("grid8" if world == 1 else "grid32")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -66,22 +89,21 @@ def main():
     from terrain_diffusion_amd.synthetic import synthetic_state_dict, synthetic_cond_grid
     from terrain_diffusion_amd.sampling import _tile_starts, _process_cond_img
 
-    # terrain-diffusion-30m base model (configs/diffusion_base/30m/diffusion_192-3.cfg:54-68)
-    BASE_CONFIG = dict(image_size=512, in_channels=5, out_channels=5, model_channels=192, model_channel_mults=[1, 2, 3, 4], layers_per_block=3,
-                       attn_resolutions=[8, 16], midblock_attention=True, concat_balance=0.5, conditional_inputs=[["tensor", 58, 1.0]], fourier_scale="pos")
-
     dev = f"cuda:{local_rank}"
     eng = get_engine(dev)
+    if workload == "cascade":
+        from terrain_diffusion_amd.cascade_bench import run_cascade
+        return run_cascade(args, eng, dev, rank, world)
     cfg = dict(BASE_CONFIG)
     model = td.EDMUnet2D(**cfg, dtype=args.dtype, device=dev)
     model.load_state_dict(synthetic_state_dict(model, seed=1234))
     sch = td.EDMDPMSolverMultistepScheduler(sigma_min=0.002, sigma_max=80.0, sigma_data=0.5)
     E = args.edm_steps
-    if args.workload == "tiles":
+    if workload == "tiles":
         H = W = 64
         tiles_per_step = args.tiles_per_step
         mp_per_step = tiles_per_step * (64 * 8) ** 2 / 1e6
-    elif args.workload == "grid32":
+    elif workload == "grid32":
         H = W = 1056
         tiles_per_step, mp_per_step = 1024, (1056 * 8) ** 2 / 1e6
     else:
@@ -90,19 +112,23 @@ def main():
     nt = len(_tile_starts(H, 64, 32))
     cond = synthetic_cond_grid(nt, nt, device=dev)
     kw = dict(cond_means=torch.zeros(7), cond_stds=torch.ones(7), noise_level=torch.tensor(0.0), histogram_raw=torch.zeros(1, 5), steps=E, tile_size=64)
-
     cond58 = torch.cat([_process_cond_img(synthetic_cond_grid(1, 1, seed=0xC0DE + j, device=dev), torch.zeros(1, 5), torch.zeros(7), torch.ones(7), 0.0)
-                        for j in range(args.tiles_per_step)]) if args.workload == "tiles" else None
+                        for j in range(max(1, args.tiles_per_step))])
+    seam = {}
+    strong = workload == "grid32"
+    if strong:
+        eng.set_option("batch_invariant", 1)   # the sharded canvas is then bit-identical to the single-GPU canvas (tests/test_parallel_cpu.py)
 
-    def one_step(i, b=None):
+    def one_step(i, b=None, wl=None):
         # different world regions each step (noise origins move), same as sampling successive regions of the world
-        if args.workload == "tiles":
+        wl = wl or workload
+        if wl == "tiles":
             b = b or tiles_per_step
             origins = [(4096 * j, 4096 * i) for j in range(b)]
             return td.sample_independent_tiles(model, sch, origins, cond58[:b], steps=E, noise_seed=42 + 5819 + rank)
-        if args.workload == "grid32":
+        if wl == "grid32":
             from terrain_diffusion_amd.parallel import sample_base_diffusion_sharded
-            return sample_base_diffusion_sharded(model, sch, (1, 5, H, W), cond, noise_seed=42 + 5819, noise_origin=(0, 4096 * i), max_batch=64, **kw)[0]
+            return sample_base_diffusion_sharded(model, sch, (1, 5, H, W), cond, noise_seed=42 + 5819, noise_origin=(0, 4096 * i), max_batch=64, stats=seam, **kw)[0]
         return td.sample_base_diffusion(model, sch, (1, 5, H, W), cond, noise_seed=42 + 5819 + rank, noise_origin=(0, 4096 * i), **kw)
 
     def sync():
@@ -115,6 +141,7 @@ def main():
     if world > 1:
         dist.barrier()
     sync()
+    seam.clear()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = one_step(args.warmup + i)
@@ -129,31 +156,36 @@ def main():
         dt = float(tt.item())
     assert bool(torch.isfinite(out).all())
     ms_per_step = dt / args.steps * 1e3
-    strong = args.workload == "grid32"
-    value = (1 if strong else world) * args.steps * mp_per_step / dt
+    weak_factor = 1 if (strong or world == 1) else world   # grid8 / tiles at N>1: every rank its own canvas / batch
+    value = weak_factor * args.steps * mp_per_step / dt
 
+    names = {"tiles": f"BASELINE configs[1] batched: terrain-diffusion-30m base U-Net, {tiles_per_step} independent single 64x64 latent tiles x {E} EDM "
+                      "DPM-Solver++ steps per step (reference latents_batch_size pattern)",
+             "grid32": f"BASELINE configs[3]: terrain-diffusion-30m base U-Net, 32x32 tile grid (1056x1056 latents) sharded over the ranks as a 2-D block mesh, "
+                       f"seam exchange of window outputs over RCCL, {E} steps",
+             "grid8": f"BASELINE configs[2]: terrain-diffusion-30m base U-Net, 8x8 tile grid (stride 32, 288x288 latents) with overlap blending, {E} steps, "
+                      "64 windows batched per solver step"}
     result = {
         "metric": "terrain megapixels/sec (decoded) at fixed steps, 30m model", "value": round(value, 4), "unit": "MP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": (f"BASELINE configs[1]: terrain-diffusion-30m base U-Net, single 64x64 latent tile x 20 EDM DPM-Solver++ steps, "
-                                f"{tiles_per_step} independent tiles batched per step (reference latents_batch_size pattern)"
-                                if args.workload == "tiles" else
-                                "BASELINE configs[3]: terrain-diffusion-30m base U-Net, 32x32 tile grid sharded over the ranks, seam exchange over RCCL, 20 steps"
-                                if args.workload == "grid32" else
-                                "BASELINE configs[2]: terrain-diffusion-30m base U-Net, 8x8 tile grid (stride 32) with overlap blending, 20 steps"),
-                   "tiles_per_step": tiles_per_step, "edm_steps": E, "decoded_mp_per_step": mp_per_step,
-                   "parallelism": f"{world} independent tile streams (one process per GPU, no data-path collective)"},
+        "config": {"workload": names[workload], "tiles_per_step": tiles_per_step, "edm_steps": E, "decoded_mp_per_step": mp_per_step,
+                   "parallelism": (f"{world} ranks, 2-D block mesh {seam.get('mesh')}, point-to-point seam exchange (no all-reduce)" if strong else
+                                   f"{world} independent streams (one process per GPU, no data-path collective)")},
     }
+    if strong:
+        result["seam"] = {"bytes_total_per_step": seam.get("seam_bytes_total", 0), "bytes_sent_rank0_per_step": seam.get("seam_bytes_sent", 0),
+                          "exchange_ms_per_step_rank0": round(seam.get("exchange_s", 0.0) / max(1, args.steps) * 1e3, 3),
+                          "windows_rank0": seam.get("windows_this_rank"), "backend": "nccl (RCCL)" if world > 1 else "none (1 rank)"}
 
     if rank == 0:
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "fp16") else PEAK_F32_TFLOPS
         flop_per_step = tiles_per_step * E * GFLOP_PER_FORWARD * 1e9 / (world if strong else 1)  # per GPU
         e2e_tflops = flop_per_step / (ms_per_step * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "td::conv_igemm_kernel", "peak": peak, "unit": "TFLOP/s", "traffic": None,
+        roof = {"bound": "mfma", "kernel": "td::conv_glds_kernel", "peak": peak, "unit": "TFLOP/s", "traffic": None,
                 "end_to_end_achieved": round(e2e_tflops, 2), "end_to_end_frac": round(e2e_tflops / peak, 4)}
-        if not args.no_kernel_profile:
-            # kernel-level: HIP events on the engine's own stream around every conv_igemm launch (eager, no graph)
+        if not args.no_kernel_profile and world == 1:
+            # kernel level: HIP events on the engine's own stream around every conv launch (eager mode, no graph), one extra step
             eng.set_option("profile", 1)
             eng.profile_read(reset=True); eng.profile_read_glds(reset=True)
             one_step(10_000)
@@ -163,38 +195,38 @@ def main():
             eng.set_option("profile", 0)
             roof.update({"all_conv_kernels_ms_per_step": round(conv_ms, 3), "all_conv_launches_per_step": conv_n,
                          "other_unet_kernel_ms_per_step": round(other_ms, 3)})
-            if g_n > 0:   # dominant kernel family: the LDS-DMA implicit-GEMM conv (terrain_diffusion_amd/csrc/conv_glds.hip)
+            if g_n > 0:   # dominant kernel family: the LDS-DMA implicit-GEMM conv (terrain_diffusion_amd/csrc/conv_glds.hip / conv_pp.hip)
                 ach = g_flop / (g_ms * 1e-3) / 1e12
-                roof.update({"kernel": "td::conv_glds_kernel", "achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches_per_step": g_n,
+                roof.update({"achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches_per_step": g_n,
                              "avg_launch_us": round(g_ms / g_n * 1e3, 3), "flop_per_launch": round(g_flop / g_n),
                              "kernel_ms_per_step": round(g_ms, 3), "share_of_unet_kernel_time": round(g_ms / (conv_ms + other_ms), 4)})
-            else:         # small-batch configurations never reach the LDS-DMA flavour
-                flop_per_launch = flop_per_step * CONV_SHARE / conv_n
-                ach = flop_per_launch / (conv_ms / conv_n * 1e-3) / 1e12
-                roof.update({"achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches_per_step": conv_n,
-                             "avg_launch_us": round(conv_ms / conv_n * 1e3, 3), "flop_per_launch": round(flop_per_launch)})
-            tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_and_mfma_util.json")
-            if os.path.exists(tpath) and args.workload == "tiles" and tiles_per_step == 64 and args.dtype == "bf16":
+            else:
+                roof.update({"achieved": roof["end_to_end_achieved"], "frac": roof["end_to_end_frac"]})
+            if os.path.exists(PROFILE_JSON) and workload in ("grid8", "tiles") and tiles_per_step == 64 and args.dtype == "bf16":
                 # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled per the
                 # MI355X guide's gfx950 correction, + WRITE_SIZE); not re-measured live (PMC collection needs rocprofv3)
-                tj = json.load(open(tpath))["kernels"]
-                ks_ = [v for k_, v in tj.items() if "conv_glds_kernel" in k_ and v.get("dispatches")]
+                tj = json.load(open(PROFILE_JSON))["kernels"]
+                ks_ = [v for k_, v in tj.items() if ("conv_glds_kernel" in k_ or "conv_pp_kernel" in k_) and v.get("dispatches") and "hbm_read_bytes_per_launch" in v]
                 n_ = sum(v["dispatches"] for v in ks_)
-                roof["traffic"] = round(sum(v["dispatches"] * (v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]) for v in ks_) / n_)
-                roof["traffic_source"] = "profiles/r01_hbm_traffic_and_mfma_util.json"
+                if n_:
+                    roof["traffic"] = round(sum(v["dispatches"] * (v["hbm_read_bytes_per_launch"] + v.get("hbm_write_bytes_per_launch", 0)) for v in ks_) / n_)
+                    roof["traffic_source"] = os.path.relpath(PROFILE_JSON, ROOT)
         else:
             roof.update({"achieved": roof["end_to_end_achieved"], "frac": roof["end_to_end_frac"]})
         result["roofline"] = roof
-        if args.workload == "tiles" and not args.no_latency:
-            # secondary number: latency of ONE tile through the same path (batch 1: launch/HBM-latency bound, not MFMA bound)
-            one_step(20_000, 1); sync()
+        if world == 1 and not args.no_latency:
+            # BASELINE configs[1] as written: ONE tile through the same path (batch 1: weight-streaming / launch-latency bound, not MFMA bound)
+            one_step(20_000, 1, "tiles"); sync()
             l0 = time.perf_counter()
             for r_ in range(3):
-                one_step(20_001 + r_, 1)
+                one_step(20_001 + r_, 1, "tiles")
             sync()
             lat = (time.perf_counter() - l0) / 3
             result["latency_single_tile_ms"] = round(lat * 1e3, 3)
             result["single_tile_mp_per_s"] = round(0.262144 / lat, 3)
+            hbm = E * WEIGHT_BYTES_BF16 / lat / 1e9
+            result["roofline_single_tile"] = {"bound": "hbm", "achieved": round(hbm, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(hbm / PEAK_HBM_GBS, 4),
+                                              "note": f"algorithmic bytes = {E} forwards x {WEIGHT_BYTES_BF16} B of bf16 weights (activations of one tile are negligible)"}
 
         if world == 1 and not args.no_cpu_baseline:
             # CPU baseline = the oracle (CPU restatement pinned to the reference) on this host's cores, bounded sample
@@ -222,12 +254,12 @@ def main():
             run(n_sample_steps)
             cdt = time.perf_counter() - c0
             per_tile = cdt / n_sample_steps * E
-            overlap = 1.0 if args.workload == "tiles" else tiles_per_step * 0.262144 / mp_per_step
+            overlap = tiles_per_step * 0.262144 / mp_per_step   # windows' area / canvas area (1 for independent tiles)
             result["cpu_baseline"] = {"value": round(0.262144 / per_tile / overlap, 6), "unit": "MP/s", "cores": best_t, "kind": "port",
                                       "host_cpus": ncpu,
-                                      "sample": f"oracle (torch fp32 CPU restatement pinned to the reference), 1 tile x {n_sample_steps} of {E} solver steps "
+                                      "sample": f"oracle (torch fp32 CPU restatement pinned to the reference), 1 window x {n_sample_steps} of {E} solver steps "
                                                 f"timed ({cdt:.1f} s on {best_t} threads, best of 8..128), scaled to {E} steps"
-                                                + ("" if args.workload == "tiles" else f" and to {tiles_per_step} overlapping tiles")}
+                                                + ("" if workload == "tiles" else f" and to the {tiles_per_step} overlapping windows of the canvas")}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -67,7 +67,7 @@ void* td_engine_stream(td_engine* e);
 int td_engine_set_option(td_engine* e, const char* key, int64_t value);
 
 /* With option "profile"=1 the samplers run eagerly (no graph) with HIP events recorded on the engine stream around every
- * conv_igemm launch (and every other U-Net kernel); this reads/reset the accumulated kernel time and launch counts. */
+ * conv launch (and every other U-Net kernel); this reads/reset the accumulated kernel time and launch counts. */
 int td_engine_profile_read(td_engine* e, double* conv_ms, int64_t* conv_launches, double* other_ms, int64_t* other_launches, int reset);
 
 /* the LDS-DMA conv kernel family (td::conv_glds_kernel) alone: summed event time, algorithmic FLOP (2*pixels*Cout*K) and launches */

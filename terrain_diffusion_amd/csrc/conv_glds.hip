@@ -374,7 +374,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
         frag_pixel<TW, TPIX>(wm * WM + i * 32, l31, img, ty, tx);
         const int n = n0 + img, y = y0 + ty, x = x0 + tx;
         const bool ok = n < p.N && y < p.H && x < p.W;
-        float ss = 0.f;
+        // sums of squares (pixel-norm statistic of the consumer) are kept per 32-cout MFMA block: the partial decomposition -- and with it
+        // the fp32 summation order the consumer sees -- is then the same for every tile shape (bn 96 / 128, 4 or 8 waves, ping-pong)
+        float ssj[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) ssj[j] = 0.f;
         if (ok) {
             const float rn = (p.res_sumsq != nullptr) ? s_rn[base_pp[i]] : 1.f;
             const int cobase = co0 + wn * WN + 4 * lh;
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
                         const bf16x4 ha = {(__bf16)va[0], (__bf16)va[1], (__bf16)va[2], (__bf16)va[3]};
                         const bf16x4 hb = {(__bf16)vb[0], (__bf16)vb[1], (__bf16)vb[2], (__bf16)vb[3]};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { const float fa = (float)ha[e], fb = (float)hb[e]; ss += fa * fa + fb * fb; }
+                        for (int e = 0; e < 4; ++e) { const float fa = (float)ha[e], fb = (float)hb[e]; ssj[j] += fa * fa + fb * fb; }
                         const u32x2 pa = __builtin_bit_cast(u32x2, ha), pb = __builtin_bit_cast(u32x2, hb);
                         unsigned a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
                         swap_halves(a0, b0); swap_halves(a1, b1);
@@ -442,16 +446,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
                         f32x4 v = {acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]};
-                        ss += epilogue4<T>(p, n, y, x, cobase + j * 32 + rg * 8, v, rn, aux[rg]);
+                        ssj[j] += epilogue4<T>(p, n, y, x, cobase + j * 32 + rg * 8, v, rn, aux[rg]);
                     }
                 }
             }
         }
         if (p.out_sumsq) {
-            ss += __shfl_xor(ss, 32);
-            if (ok && lh == 0) {
-                const size_t pix = ((size_t)n * p.H + y) * p.W + x;
-                p.out_sumsq[(size_t)(ntile * WAVES_N + wn) * M + pix] = ss;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float ss = ssj[j] + __shfl_xor(ssj[j], 32);
+                if (ok && lh == 0 && co0 + wn * WN + j * 32 < p.CoutPad) {
+                    const size_t pix = ((size_t)n * p.H + y) * p.W + x;
+                    p.out_sumsq[(size_t)((co0 + wn * WN) / 32 + j) * M + pix] = ss;
+                }
             }
         }
     }

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
         const int co0 = ent * BN;
         f32x4 ca[2], cb[2];
         u32x4 rw[2];
-        int pixv[MT]; bool okv[MT]; float rnv[MT], ssv[MT];
+        int pixv[MT]; bool okv[MT]; float rnv[MT], ssv[MT][NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             int img, ty, tx;
@@ -299,7 +299,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
             okv[i] = y < p.H && x < p.W;
             pixv[i] = okv[i] ? (en0 * p.H + y) * p.W + x : 0;
             rnv[i] = (p.res_sumsq != nullptr) ? ((const float*)(smem + RN_BASE + erb * (NPATCH * 4)))[base_pp[i]] : 1.f;
-            ssv[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ssv[i][j] = 0.f;
         }
         const int cobase = co0 + wn * WN + 4 * lh;
         auto fetch = [&](int u, int s) {
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
                 const bf16x4 ha = {(__bf16)va[0], (__bf16)va[1], (__bf16)va[2], (__bf16)va[3]};
                 const bf16x4 hb = {(__bf16)vb[0], (__bf16)vb[1], (__bf16)vb[2], (__bf16)vb[3]};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float fa = (float)ha[e], fb = (float)hb[e]; ssv[i] += fa * fa + fb * fb; }
+                for (int e = 0; e < 4; ++e) { const float fa = (float)ha[e], fb = (float)hb[e]; ssv[i][j] += fa * fa + fb * fb; }
                 const u32x2 pa = __builtin_bit_cast(u32x2, ha), pb2 = __builtin_bit_cast(u32x2, hb);
                 unsigned a0 = pa[0], a1 = pa[1], b0 = pb2[0], b1 = pb2[1];
                 swap_halves(a0, b0); swap_halves(a1, b1);
@@ -363,10 +364,12 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
         }
         if (p.out_sumsq) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const float ss = ssv[i] + __shfl_xor(ssv[i], 32);
-                if (okv[i] && lh == 0) p.out_sumsq[(size_t)(ent * WAVES_N + wn) * M + pixv[i]] = ss;
-            }
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {  // one partial per 32-cout MFMA block, as in conv_glds.hip (tile-shape independent order)
+                    const float ss = ssv[i][j] + __shfl_xor(ssv[i][j], 32);
+                    if (okv[i] && lh == 0 && co0 + wn * WN + j * 32 < p.CoutPad) p.out_sumsq[(size_t)((co0 + wn * WN) / 32 + j) * M + pixv[i]] = ss;
+                }
         }
         PP_ZERO_ACC();
     };

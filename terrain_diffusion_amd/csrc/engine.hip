@@ -498,10 +498,12 @@ static int new_buf(Plan& pl, size_t bytes, void** out) {
 struct SegSpec { const Tensor* t; int C; int taps; int resample; int xform; float scale; };
 
 static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
-    char key[96];
-    snprintf(key, sizeof key, "%d_%d_%d_%d%d%d_%lld_%d_%d", N, H, W, (int)u->eng->option("batch_invariant", 0), (int)u->eng->option("glds", 1),
-             (int)u->eng->option("splitk", 1) + 2 * (int)u->eng->option("producer_act", 1), (long long)u->eng->option("glds_min_wgs", 8),
-             (int)u->eng->option("glds_variant", -1), (int)u->eng->option("glds_bn", 0) + 1000 * (int)u->eng->option("pp", 0) + 10000 * (int)u->eng->option("pp_min_items_per_cu", 2));
+    // every option the plan builder reads is part of the cache key (a plan built under other options must never be reused)
+    static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn", "pp",
+                                               "pp_min_items_per_cu", "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
+                                               "bn128_min_wgs"};
+    std::string key = std::to_string(N) + "_" + std::to_string(H) + "_" + std::to_string(W);
+    for (const char* o : kPlanOptions) key += "_" + std::to_string((long long)u->eng->option(o, -7));
     auto it = u->plans.find(key);
     if (it != u->plans.end()) { it->second->last_use = ++u->use_clock; *out = it->second.get(); return TD_OK; }
     if (N < 1 || N > 1023 || H > 1023 || W > 1023) return fail(TD_ERR_ARG, "batch/size out of range");
@@ -632,7 +634,9 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
             if (use_splitk && !u->eng->option("batch_invariant", 0) && base < splitk_target / 2 && kgroups > 1) p.ksplit = (int)std::min<int64_t>(kgroups, (splitk_target + base - 1) / base);
         }
         p.epi = epi; p.out_f32 = out_f32 ? 1 : 0; p.clip = clip; p.zeros = u->eng->zeros;
-        const int out_parts = p.ksplit > 1 ? (cw.cout_pad + 255) / 256 : p.n_ntiles * 2;
+        // pixel-norm partials of the output: LDS-DMA / ping-pong flavours write one per 32-cout MFMA block (independent of the tile shape),
+        // the per-tap flavour one per (cout tile, wave column), the split-K reduce kernel one per 256 couts
+        const int out_parts = p.ksplit > 1 ? (cw.cout_pad + 255) / 256 : (op.flavor >= 2 ? cw.cout_pad / 32 : p.n_ntiles * 2);
         if (out_f32) {
             outT->C = cw.cout; outT->cstride = 8; outT->H = h; outT->W = w; outT->sumsq = nullptr;
             if ((rc = new_buf(pl, (size_t)N * h * w * 8 * 4, &outT->ptr))) return rc;
@@ -1027,7 +1031,7 @@ int td_unet_read_activation(td_unet* u, int n, int H, int W, const char* label, 
     if (!strncmp(label, "sumsq:", 6)) {
         for (auto& op : pl->ops) {
             if (op.kind != Op::CONV || op.label != label + 6 || !op.p.out_sumsq) continue;
-            const int parts = op.p.ksplit > 1 ? (op.p.CoutPad + 255) / 256 : op.p.n_ntiles * 2;
+            const int parts = op.p.ksplit > 1 ? (op.p.CoutPad + 255) / 256 : (op.flavor >= 2 ? op.p.CoutPad / 32 : op.p.n_ntiles * 2);
             const size_t M = (size_t)n * op.out_H * op.out_W;
             dims[0] = parts; dims[1] = n; dims[2] = op.out_H; dims[3] = op.out_W;
             if ((int64_t)(parts * M) > capacity) return fail(TD_ERR_ARG, "capacity");

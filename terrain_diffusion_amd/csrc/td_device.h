@@ -44,7 +44,7 @@ struct ConvParams {
     float res_inv_c;
     float res_scale;      // 0.7/sqrt(0.58) (conv weights carry 0.3/sqrt(0.58))
     float clip;           // <=0: no clip
-    float* out_sumsq;     // [n_ntiles*WAVES_N][N*H*W] or null
+    float* out_sumsq;     // [parts][N*H*W] or null; parts: CoutPad/32 (conv_glds / conv_pp), n_ntiles*WAVES_N (conv_igemm), CoutPad/256 (split-K reduce)
     float* partial;       // split-K workspace [ksplit][N*H*W][CoutPad] fp32
     void* out2;           // optional second output, same layout as out: mp_silu(out2_scale * out) -- the consumer's activation, done once here
     float out2_scale;

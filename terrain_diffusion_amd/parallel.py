@@ -145,7 +145,7 @@ def engine_fns(model, scheduler, plan, cond_inputs, *, cond_means, cond_stds, no
 
 def sample_base_diffusion_sharded(model, scheduler, shape, cond_inputs, *, cond_means, cond_stds, noise_level=0.0, histogram_raw, steps=15,
                                   tile_size=64, noise_seed=42 + 5819, noise_origin=(0, 0), max_batch=64, group=None, gather_to=None,
-                                  sample_fn=None, blend_fn=None, normalize_fn=None):
+                                  sample_fn=None, blend_fn=None, normalize_fn=None, stats=None):
     """Sharded sample_base_diffusion (terrain_diffusion/training/evaluation/sample_diffusion_base.py:115-168).
     Returns (region_tensor (C,h,w), (y0,y1,x0,x1)) for this rank, or the assembled (1,C,H,W) on rank `gather_to`.
     sample_fn / blend_fn / normalize_fn default to the HIP engine; tests inject CPU stand-ins to exercise the plumbing under gloo."""
@@ -160,7 +160,22 @@ def sample_base_diffusion_sharded(model, scheduler, shape, cond_inputs, *, cond_
                                                        histogram_raw=histogram_raw, steps=steps, channels=C_, noise_seed=noise_seed, noise_origin=noise_origin,
                                                        max_batch=max_batch)
     my_tiles = sample_fn(plan.windows[rank])
+    if stats is not None:   # seam accounting for bench.py: bytes this rank sends / receives and the wall time of the exchange itself
+        import time
+        if my_tiles.is_cuda:
+            torch.cuda.synchronize(my_tiles.device)
+        t0 = time.perf_counter()
     have = exchange_windows(plan, rank, my_tiles, group) if world > 1 else {w: my_tiles[i] for i, w in enumerate(plan.windows[rank])}
+    if stats is not None:
+        if my_tiles.is_cuda:
+            torch.cuda.synchronize(my_tiles.device)
+        sb = plan.seam_bytes(C_)
+        stats["exchange_s"] = stats.get("exchange_s", 0.0) + (time.perf_counter() - t0)
+        stats["seam_bytes_sent"] = sum(v for (s_, d_), v in sb.items() if s_ == rank)
+        stats["seam_bytes_received"] = sum(v for (s_, d_), v in sb.items() if d_ == rank)
+        stats["seam_bytes_total"] = sum(sb.values())
+        stats["mesh"] = [plan.pr, plan.pc]
+        stats["windows_this_rank"] = len(plan.windows[rank])
     region = blend_region(plan, rank, have, blend_fn, normalize_fn, C_, 1.0 / sd)
     if gather_to is None:
         return region, plan.regions[rank]

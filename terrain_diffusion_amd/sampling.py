@@ -33,13 +33,23 @@ def _process_cond_img(cond_img, histogram_raw, cond_means, cond_stds, noise_leve
     cond_img = torch.as_tensor(cond_img, dtype=torch.float32).cpu()
     means = torch.as_tensor(cond_means, dtype=torch.float32).view(1, -1, 1, 1)
     stds = torch.as_tensor(cond_stds, dtype=torch.float32).view(1, -1, 1, 1)
-    if torch.isnan(cond_img).any():
-        raise NotImplementedError("NaN conditioning fill is not on the accelerated path")
     cond_img = (cond_img - means) / stds
+    # NaN fill exactly as the reference writes it (sample_diffusion_base.py:36-46, batch-dimension indexing and all):
+    # sample 0's NaNs become cond_means[0], sample 1's cond_means[1]; NaN climate means are drawn from torch's global generator there,
+    # which no other implementation can reproduce -> here they come from the portable stream (seed 9999 + count), documented deviation
+    cm = torch.as_tensor(cond_means, dtype=torch.float32).flatten()
+    cond_img[0:1] = torch.nan_to_num(cond_img[0:1], nan=float(cm[0]))
+    cond_img[1:2] = torch.nan_to_num(cond_img[1:2], nan=float(cm[1]))
     B = cond_img.shape[0]
     nl = (torch.as_tensor(noise_level, dtype=torch.float32) - 0.5) * np.sqrt(12)
     hist = torch.as_tensor(histogram_raw, dtype=torch.float32)
-    parts = [cond_img[:, 0:1].flatten(1), cond_img[:, 1:2].flatten(1), cond_img[:, 2:6, 1:3, 1:3].mean(dim=(2, 3)).flatten(1),
+    clim = cond_img[:, 2:6, 1:3, 1:3].mean(dim=(2, 3))
+    nan_mask = torch.isnan(clim)
+    if bool(nan_mask.any()):
+        from .noise import standard_normal
+        cnt = int(nan_mask.sum())
+        clim[nan_mask] = torch.from_numpy(standard_normal(9999 + cnt, (cnt,), dtype=np.float32))
+    parts = [cond_img[:, 0:1].flatten(1), cond_img[:, 1:2].flatten(1), clim.flatten(1),
              cond_img[:, 6:7].flatten(1), hist.view(-1, hist.shape[-1]).expand(B, -1), nl.view(-1, 1).expand(B, 1)]
     n = len(parts)
     Cc = math.sqrt(sum(p.shape[1] for p in parts) / (n * (1.0 / n) ** 2))
@@ -105,6 +115,7 @@ def sample_tiles_edm(model, scheduler, x, cond, steps, cond_img=None):
     (coarse stage: world_pipeline.py:946 `torch.cat([scaled_in, cond_img], dim=1)`)."""
     scheduler.set_timesteps(steps)
     sig = scheduler.sigmas.to(torch.float32).cpu().contiguous()
+    model.engine.set_option("solver_order", int(getattr(scheduler.config, "solver_order", 2)))
     n, _, H, W = x.shape
     cimg = 0 if cond_img is None else cond_img.shape[1]
     check(lib().td_sample_edm_img(model._h, n, H, W, steps, ptr(sig), float(scheduler.config.sigma_data), ptr(cond), ptr(cond_img), cimg, ptr(x)))
@@ -126,10 +137,11 @@ def consistency_step(model, t, sigma_data, sample, z, cond=None, cond_img=None):
 @torch.no_grad()
 def sample_base_diffusion(model, scheduler, shape, cond_inputs, *, cond_means, cond_stds, noise_level=0.0, histogram_raw, dtype=torch.float32,
                           steps=15, guide_model=None, guidance_scale=1.0, generator=None, tile_size=None, weight_window_fn=None,
-                          noise_seed=42 + 5819, noise_origin=(0, 0), tiles=None, max_batch=64, return_canvas=False):
-    """Reference signature + (noise_seed, noise_origin, tiles, max_batch, return_canvas).
+                          noise_seed=42 + 5819, noise_origin=(0, 0), tiles=None, max_batch=64, return_canvas=False, return_windows=False):
+    """Reference signature + (noise_seed, noise_origin, tiles, max_batch, return_canvas, return_windows).
     `tiles`: optional subset of (ic, jc) window indices to run (multi-GPU sharding); `return_canvas` returns the
-    un-normalised (C+1,H,W) accumulator instead of output/weights/sigma_data."""
+    un-normalised (C+1,H,W) accumulator instead of output/weights/sigma_data; `return_windows` additionally returns the
+    pre-blend window outputs [(ic, jc)] -> (C, T, T) device tensors (parity tests look at windows before the blend mixes them)."""
     if guide_model is not None and guidance_scale != 1.0:
         raise NotImplementedError("autoguidance is not on the accelerated path yet")
     if weight_window_fn is not None:
@@ -156,19 +168,24 @@ def sample_base_diffusion(model, scheduler, shape, cond_inputs, *, cond_means, c
     all_tiles = [(ic, jc) for ic in range(len(h_starts)) for jc in range(len(w_starts))]
     run = all_tiles if tiles is None else [t for t in all_tiles if t in set(tiles)]
     canvas = torch.zeros((C_ + 1, H, W), dtype=torch.float32, device=dev)
+    windows = {}
     for b0 in range(0, len(run), max_batch):
         chunk = run[b0:b0 + max_batch]
         origins = [(noise_origin[0] + h_starts[ic], noise_origin[1] + w_starts[jc]) for ic, jc in chunk]
         # initial_noise[..., i0:i1, j0:j1] of one shared field (sample_diffusion_base.py:124,145) == windows of the absolute field
-        x = _noise.gaussian_noise_patches(noise_seed, origins, th, tw, channels=C_, tile_h=64, tile_w=64, scale=sigma0, device=dev)
+        # the bounded sampler's noise field is this package's own convention (the reference draws torch.randn here): 64x64 noise tiles,
+        # or one tile size that holds the window when the window is larger
+        nth, ntw = max(64, th), max(64, tw)
+        x = _noise.gaussian_noise_patches(noise_seed, origins, th, tw, channels=C_, tile_h=nth, tile_w=ntw, scale=sigma0, device=dev)
         cond = _tile_conditioning(cond_inputs, chunk, histogram_raw, cond_means, cond_stds, noise_level).to(dev).contiguous()
         sample_tiles_edm(model, scheduler, x, cond, steps)
         if tile_size is None:
             return x
+        if return_windows:
+            windows.update({t: x[k].clone() for k, t in enumerate(chunk)})
         blend_windows(eng, canvas, x, chunk, h_starts, w_starts, tile_size, accumulate=True)
-    if return_canvas:
-        return canvas
-    return blend_normalize(eng, canvas, 1.0 / sd)[None]
+    out = canvas if return_canvas else blend_normalize(eng, canvas, 1.0 / sd)[None]
+    return (out, windows) if return_windows else out
 
 
 @torch.no_grad()

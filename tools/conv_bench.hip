@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
     p.epi = epi; p.out = out; p.out_cstride = Cout;
     { void* z; CK(hipMalloc(&z, 4096)); CK(hipMemset(z, 0, 4096)); p.zeros = z; }
     if (epi == EPI_EMB_SILU) { float* cv; CK(hipMalloc(&cv, (size_t)N * Cout * 4)); std::vector<float> hc((size_t)N * Cout, 1.01f); CK(hipMemcpy(cv, hc.data(), hc.size() * 4, hipMemcpyHostToDevice)); p.cvec = cv; p.cvec_stride = Cout; }
-    if (epi == EPI_RESIDUAL) { void* r; float* ssq; CK(hipMalloc(&r, M * Cout * 2)); CK(hipMemcpy(r, hx.data(), std::min(hx.size(), M * Cout) * 2, hipMemcpyHostToDevice)); CK(hipMalloc(&ssq, M * 8 * 4)); CK(hipMemset(ssq, 0, M * 8 * 4));
+    if (epi == EPI_RESIDUAL) { void* r; float* ssq; CK(hipMalloc(&r, M * Cout * 2)); CK(hipMemcpy(r, hx.data(), std::min(hx.size(), M * Cout) * 2, hipMemcpyHostToDevice)); CK(hipMalloc(&ssq, M * (Cout / 32 + 8) * 4)); CK(hipMemset(ssq, 0, M * (Cout / 32 + 8) * 4));
         p.res = r; p.res_cstride = Cout; p.res_Hs = H; p.res_Ws = W; p.res_scale = 0.9f; p.clip = 256.f; p.out_sumsq = ssq; }
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -60,12 +60,12 @@ int main(int argc, char** argv) {
         CK(launch_conv_pp(p, bn, 256, st)); CK(hipStreamSynchronize(st));
         CK(hipMemcpy(o5.data(), out, o5.size() * 2, hipMemcpyDeviceToHost));
         std::vector<float> s5, s2;
-        if (p.out_sumsq) { s5.resize(M * 8); CK(hipMemcpy(s5.data(), p.out_sumsq, s5.size() * 4, hipMemcpyDeviceToHost)); }
+        if (p.out_sumsq) { s5.resize(M * (Cout / 32)); CK(hipMemcpy(s5.data(), p.out_sumsq, s5.size() * 4, hipMemcpyDeviceToHost)); }
         CK(hipMemset(out, 0, M * Cout * 2));
         ConvParams q = p; q.tiles_y = (H + 15) / 16;
         CK(launch_conv_glds(q, narrow, bn, 0, st)); CK(hipStreamSynchronize(st));
         CK(hipMemcpy(o2.data(), out, o2.size() * 2, hipMemcpyDeviceToHost));
-        if (p.out_sumsq) { s2.resize(M * 8); CK(hipMemcpy(s2.data(), p.out_sumsq, s2.size() * 4, hipMemcpyDeviceToHost)); }
+        if (p.out_sumsq) { s2.resize(M * (Cout / 32)); CK(hipMemcpy(s2.data(), p.out_sumsq, s2.size() * 4, hipMemcpyDeviceToHost)); }
         size_t bad = 0, first = 0; for (size_t i = 0; i < o5.size(); ++i) if (o5[i] != o2[i]) { if (!bad) first = i; ++bad; }
         size_t bads = 0; for (size_t i = 0; i < s5.size(); ++i) if (memcmp(&s5[i], &s2[i], 4)) ++bads;
         size_t nz = 0; for (auto v : o2) nz += (v & 0x7fff) != 0;
