@@ -120,6 +120,10 @@ int td_noise_patches(td_engine* e, uint64_t base_seed, int n_windows, const int6
  * sigmas_host: n_steps+1 values (last = 0). */
 int td_sample_edm(td_unet* u, int n, int H, int W, int n_steps, const float* sigmas_host, float sigma_data,
                   const float* cond, float* x);
+/* Autoguidance (sample_diffusion_base.py:105-110,155-160): F = F_guide + scale * (F_main - F_guide) in every step; the guide is a second,
+ * smaller EDMUnet2D taking the same inputs (configs/diffusion_base/30m/diffusion_128-3.cfg), created on the same engine with the same dtype. */
+int td_sample_edm_guided(td_unet* u, td_unet* guide, float guidance_scale, int n, int H, int W, int n_steps, const float* sigmas_host,
+                         float sigma_data, const float* cond, float* x);
 /* One trig-flow consistency phase (sample_diffusion_base.py:248-257, world_pipeline.py:1097-1129):
  *   x_t = cos t*sample + sin t*sigma_d*z ; out = cos t*x_t + sin t*sigma_d*model(x_t/sigma_d, t, cond)
  * sample may be NULL (zeros, first phase). */
@@ -145,6 +149,20 @@ int td_blend_windows(td_engine* e, float* canvas, int C, int Hc, int Wc, int siz
 int td_blend_normalize(td_engine* e, const float* canvas, int C, int Hc, int Wc, float scale, float* out);
 /* linear_weight_window(size) (world_pipeline.py:117-124) -> out[size*size] */
 int td_linear_weight_window(td_engine* e, int size, float* out);
+
+/* ---- output composition after the decoder ---------------------------------------------------------
+ * Separable gather: out[c][yo][xo] = sum_a wy[yo][a] * ( sum_b wx[xo][b] * in[c][iy[yo][a]][ix[xo][b]] ), rows first.  The tap tables
+ * (host int32 / float arrays of Hout*Ky and Wout*Kx entries) carry bilinear resize with align_corners=False, its anti-aliased form and the
+ * reflect-padded Gaussian blur -- torchvision.transforms.functional.resize / gaussian_blur as used by laplacian_encode / laplacian_decode
+ * (terrain_diffusion/data/laplacian_encoder.py:62-137).  in/out: [C][H][W] fp32, host or device. */
+int td_resample2d(td_engine* e, const float* in, int C, int Hin, int Win, int Hout, int Wout, const int32_t* iy_host, const float* wy_host, int Ky,
+                  const int32_t* ix_host, const float* wx_host, int Kx, float* out);
+/* (r0/r1)*std+mean + lowres_up over a packed (2,Hp,Wp) decoder slice -> (Hp,Wp): the `decoded` image inside laplacian_denoise
+ * (laplacian_encoder.py:134-137 via world_pipeline.py:1300-1306).  Device buffers. */
+int td_residual_plus(td_engine* e, const float* packed, const float* lowres_up, int Hp, int Wp, float res_mean, float res_std, float* out);
+/* elev = sign(s) * s^2, s = (r0/r1)*std+mean + lowres_up, cropped to [oi,oi+h) x [oj,oj+w)  (world_pipeline.py:1300,1308-1312).  Device buffers. */
+int td_elev_finish(td_engine* e, const float* packed, const float* lowres_up, int Hp, int Wp, int oi, int oj, int h, int w, float res_mean,
+                   float res_std, float* out);
 
 #ifdef __cplusplus
 }

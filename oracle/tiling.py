@@ -96,7 +96,7 @@ def initial_noise_field(seed, H, W, channels=5, y0=0, x0=0):
 def sample_base_diffusion_tiled(model, shape, cond_inputs, *, steps=20, tile_size=64, noise_seed=42 + 5819,
                                 cond_means=None, cond_stds=None, histogram_raw=None, noise_level=0.0,
                                 sigma_min=0.002, sigma_max=80.0, sigma_data=0.5, rho=7.0,
-                                tiles=None, return_parts=False):
+                                tiles=None, return_parts=False, guide_model=None, guidance_scale=1.0):
     """sample_diffusion_base.py:115-168 (B must be 1).  `tiles` optionally restricts to a subset of
     (ic, jc) tile indices (used for sharding tests); returns output/output_weights/sigma_data or parts."""
     B, C, H, W = shape
@@ -127,6 +127,9 @@ def sample_base_diffusion_tiled(model, shape, cond_inputs, *, steps=20, tile_siz
                 xin = schedule.precondition_inputs(x, sigma, sigma_data)
                 cn = schedule.trigflow_t(sigma.view(-1).expand(B), sigma_data)
                 F_ = model(xin, cn, tile_cond)
+                if guide_model is not None and guidance_scale != 1.0:   # autoguidance, sample_diffusion_base.py:155-160
+                    F_g = guide_model(xin, cn, tile_cond)
+                    F_ = F_g + guidance_scale * (F_ - F_g)
                 x, m_prev = schedule.dpm_step(sigmas, i, orders[i], x, F_, m_prev, sigma_data)
             output[..., i0:i0 + tile_size, j0:j0 + tile_size] += x * weights
             output_weights[..., i0:i0 + tile_size, j0:j0 + tile_size] += weights

@@ -48,12 +48,16 @@ _SIGS = {
     "td_standard_normal": (C.c_int, [_P, C.c_uint64, C.c_int64, _P]),
     "td_noise_patches": (C.c_int, [_P, C.c_uint64, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "td_sample_edm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, _P]),
+    "td_sample_edm_guided": (C.c_int, [_P, _P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, _P]),
     "td_sample_consistency": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P]),
     "td_sample_edm_img": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, _P, C.c_int, _P]),
     "td_sample_consistency_img": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, C.c_int, _P]),
     "td_blend_windows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int]),
     "td_blend_normalize": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "td_linear_weight_window": (C.c_int, [_P, C.c_int, _P]),
+    "td_resample2d": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
+    "td_residual_plus": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
+    "td_elev_finish": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -19,6 +19,7 @@
 #include "conv_glds.hip"
 #include "conv_pp.hip"
 #include "small_kernels.hip"
+#include "compose_kernels.hip"
 
 using namespace td;
 
@@ -191,6 +192,9 @@ struct Plan {
     std::vector<float> graph_sigmas;
     float graph_sigma_data = 0.f;
     int graph_solver_order = 0;
+    const void* graph_guide = nullptr;       // guide plan / its modulation buffer / scale the captured graph was built with (autoguidance)
+    const void* graph_guide_cvec = nullptr;
+    float graph_gscale = 0.f;
     size_t bytes = 0;          // device memory owned by this plan (activations, partials, sampler state)
     uint64_t last_use = 0;     // LRU stamp (td_unet::use_clock)
     void drop_graph() { if (graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; } }
@@ -626,8 +630,11 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
             p.tiles_x = (w + TW - 1) / TW; p.tiles_y = (h + TH - 1) / TH; p.img_groups = (N + NIMG - 1) / NIMG;
             const int64_t mt = (int64_t)p.tiles_x * p.tiles_y * p.img_groups;
             op.bn = 64;
-            if (cw.cout_pad % 128 == 0 && mt * (cw.cout_pad / 128) >= bn128_min) op.bn = 128;
-            else if (cw.cout_pad % 96 == 0 && mt * (cw.cout_pad / 96) >= bn128_min) op.bn = 96;
+            const bool inv0 = u->eng->option("batch_invariant", 0) != 0;
+            // batch_invariant: the cout tile must not depend on the batch size either -- this flavour keeps its pixel-norm partials per
+            // (cout tile, wave column), so a different bn would change the order in which the consumer adds the sums of squares
+            if (cw.cout_pad % 128 == 0 && (inv0 || mt * (cw.cout_pad / 128) >= bn128_min)) op.bn = 128;
+            else if (cw.cout_pad % 96 == 0 && (inv0 || mt * (cw.cout_pad / 96) >= bn128_min)) op.bn = 96;
             p.n_ntiles = cw.cout_pad / op.bn;
             const int64_t base = mt * p.n_ntiles;
             p.ksplit = 1;
@@ -1109,9 +1116,15 @@ static int stage_cond_img(td_unet* u, Plan& pl, int n, int HW, const float* cond
     return TD_OK;
 }
 
-int td_sample_edm_img(td_unet* u, int n, int H, int W, int n_steps, const float* sigmas_host, float sigma_data, const float* cond,
-                      const float* cond_img, int cimg, float* x) {
+static int sample_edm_impl(td_unet* u, td_unet* guide, float gscale, int n, int H, int W, int n_steps, const float* sigmas_host, float sigma_data,
+                           const float* cond, const float* cond_img, int cimg, float* x) {
     DevGuard dg_(u->eng->device);
+    if (guide) {
+        if (!guide->finalized) return fail(TD_ERR_STATE, "finalize the guide model first");
+        if (guide->eng != u->eng || guide->bf16 != u->bf16) return fail(TD_ERR_ARG, "guide model must live on the same engine and use the same dtype");
+        if (guide->cfg.in_channels != u->cfg.in_channels || guide->cfg.out_channels != u->cfg.out_channels || guide->cond_row_len != u->cond_row_len)
+            return fail(TD_ERR_ARG, "guide model must take the same inputs as the main model");
+    }
     if (!u->finalized) return fail(TD_ERR_STATE, "finalize first");
     if (n_steps < 1) return fail(TD_ERR_ARG, "n_steps");
     Plan* pl;
@@ -1133,6 +1146,12 @@ int td_sample_edm_img(td_unet* u, int n, int H, int W, int n_steps, const float*
     std::vector<float> ts(n_steps);
     for (int i = 0; i < n_steps; ++i) ts[i] = atanf(sigmas_host[i] / sigma_data);  // trigflow_precondition_noise (dpmsolver.py:240-242)
     if ((rc = compute_cvecs(u, *pl, ts, (const float*)pl->cond->p))) return rc;
+    Plan* gpl = nullptr;
+    if (guide) {
+        if ((rc = build_plan(guide, n, H, W, &gpl))) return rc;
+        if ((rc = stage_cond_img(guide, *gpl, n, HW, cond_img, cimg, C, hold))) return rc;
+        if ((rc = compute_cvecs(guide, *gpl, ts, (const float*)pl->cond->p))) return rc;
+    }
     std::vector<SchedCoef> ks;
     const int solver_order = (int)e->option("solver_order", 2);
     if (solver_order != 1 && solver_order != 2) return fail(TD_ERR_ARG, "solver_order must be 1 or 2");
@@ -1142,11 +1161,17 @@ int td_sample_edm_img(td_unet* u, int n, int H, int W, int n_steps, const float*
     auto enqueue = [&]() -> int {
         if (u->bf16) hipLaunchKernelGGL(prep_input_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (__bf16*)pl->xin, n, C, HW, u->chunk, c_in0, Cin);
         else hipLaunchKernelGGL(prep_input_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (float*)pl->xin, n, C, HW, u->chunk, c_in0, Cin);
+        if (gpl) {
+            if (u->bf16) hipLaunchKernelGGL(prep_input_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (__bf16*)gpl->xin, n, C, HW, u->chunk, c_in0, Cin);
+            else hipLaunchKernelGGL(prep_input_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (float*)gpl->xin, n, C, HW, u->chunk, c_in0, Cin);
+        }
+        const float* Fg = gpl ? (const float*)gpl->F : nullptr;
         for (int i = 0; i < n_steps; ++i) {
             int r = run_unet(u, *pl, i);
             if (r) return r;
-            if (u->bf16) hipLaunchKernelGGL(dpm_step_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (float*)pl->x->p, (float*)pl->m1->p, (const float*)pl->F, (__bf16*)pl->xin, n, C, HW, 8, u->chunk, ks[i]);
-            else hipLaunchKernelGGL(dpm_step_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (float*)pl->x->p, (float*)pl->m1->p, (const float*)pl->F, (float*)pl->xin, n, C, HW, 8, u->chunk, ks[i]);
+            if (gpl && (r = run_unet(guide, *gpl, i))) return r;
+            if (u->bf16) hipLaunchKernelGGL(dpm_step_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (float*)pl->x->p, (float*)pl->m1->p, (const float*)pl->F, (__bf16*)pl->xin, n, C, HW, 8, u->chunk, ks[i], Fg, gscale, gpl ? (__bf16*)gpl->xin : (__bf16*)nullptr);
+            else hipLaunchKernelGGL(dpm_step_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (float*)pl->x->p, (float*)pl->m1->p, (const float*)pl->F, (float*)pl->xin, n, C, HW, 8, u->chunk, ks[i], Fg, gscale, gpl ? (float*)gpl->xin : (float*)nullptr);
         }
         HIP_TRY(hipGetLastError());
         return TD_OK;
@@ -1155,7 +1180,10 @@ int td_sample_edm_img(td_unet* u, int n, int H, int W, int n_steps, const float*
     const bool use_graph = e->option("graph", 1) != 0 && e->option("profile", 0) == 0;
     if (use_graph) {
         std::vector<float> sg(sigmas_host, sigmas_host + n_steps + 1);
-        if (!pl->graph || pl->graph_sigmas != sg || pl->graph_sigma_data != sigma_data || pl->graph_solver_order != solver_order) {
+        // the guide's plan can be evicted / its buffers re-allocated independently of this plan: key the graph on them too
+        const void* gkey = gpl ? (const void*)gpl->cvec->p : nullptr;
+        if (!pl->graph || pl->graph_sigmas != sg || pl->graph_sigma_data != sigma_data || pl->graph_solver_order != solver_order ||
+            pl->graph_guide != (const void*)gpl || pl->graph_guide_cvec != gkey || pl->graph_gscale != gscale) {
             pl->drop_graph();
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -1167,6 +1195,7 @@ int td_sample_edm_img(td_unet* u, int n, int H, int W, int n_steps, const float*
             (void)hipGraphDestroy(g);
             if (ie != hipSuccess) { pl->graph = nullptr; return fail(TD_ERR_HIP, std::string("graph instantiate: ") + hipGetErrorString(ie)); }
             pl->graph_sigmas = sg; pl->graph_sigma_data = sigma_data; pl->graph_solver_order = solver_order;
+            pl->graph_guide = gpl; pl->graph_guide_cvec = gkey; pl->graph_gscale = gscale;
         }
         HIP_TRY(hipGraphLaunch(pl->graph, st));
     } else if ((rc = enqueue())) return rc;
@@ -1175,8 +1204,17 @@ int td_sample_edm_img(td_unet* u, int n, int H, int W, int n_steps, const float*
     return TD_OK;
 }
 
+int td_sample_edm_img(td_unet* u, int n, int H, int W, int n_steps, const float* sigmas_host, float sigma_data, const float* cond,
+                      const float* cond_img, int cimg, float* x) {
+    return sample_edm_impl(u, nullptr, 1.f, n, H, W, n_steps, sigmas_host, sigma_data, cond, cond_img, cimg, x);
+}
 int td_sample_edm(td_unet* u, int n, int H, int W, int n_steps, const float* sigmas_host, float sigma_data, const float* cond, float* x) {
-    return td_sample_edm_img(u, n, H, W, n_steps, sigmas_host, sigma_data, cond, nullptr, 0, x);
+    return sample_edm_impl(u, nullptr, 1.f, n, H, W, n_steps, sigmas_host, sigma_data, cond, nullptr, 0, x);
+}
+int td_sample_edm_guided(td_unet* u, td_unet* guide, float guidance_scale, int n, int H, int W, int n_steps, const float* sigmas_host, float sigma_data,
+                         const float* cond, float* x) {
+    if (!guide) return fail(TD_ERR_ARG, "null guide model");
+    return sample_edm_impl(u, guide, guidance_scale, n, H, W, n_steps, sigmas_host, sigma_data, cond, nullptr, 0, x);
 }
 
 int td_sample_consistency_img(td_unet* u, int n, int H, int W, float t, float sigma_data, const float* sample, const float* z, const float* cond,
@@ -1381,6 +1419,51 @@ int td_blend_normalize(td_engine* e, const float* canvas, int C, int Hc, int Wc,
     hipLaunchKernelGGL(blend_normalize_kernel, grid1((size_t)Hc * Wc), dim3(256), 0, e->stream, (const float*)dc, (float*)os.dev, C, Hc * Wc, scale);
     HIP_TRY(hipGetLastError());
     if ((rc = out_finish(e, os))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return TD_OK;
+}
+
+// ---- output composition
+int td_resample2d(td_engine* e, const float* in, int C, int Hin, int Win, int Hout, int Wout, const int32_t* iy, const float* wy, int Ky,
+                  const int32_t* ix, const float* wx, int Kx, float* out) {
+    DevGuard dg_(e->device);
+    if (C < 1 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1 || Ky < 1 || Kx < 1) return fail(TD_ERR_ARG, "td_resample2d: bad geometry");
+    for (int i = 0; i < Hout * Ky; ++i) if (iy[i] < 0 || iy[i] >= Hin) return fail(TD_ERR_ARG, "td_resample2d: row tap out of range");
+    for (int i = 0; i < Wout * Kx; ++i) if (ix[i] < 0 || ix[i] >= Win) return fail(TD_ERR_ARG, "td_resample2d: column tap out of range");
+    hipStream_t st = e->stream;
+    std::vector<Buf> hold;
+    const void *din, *diy, *dwy, *dix, *dwx;
+    int rc;
+    if ((rc = to_device(e, in, (size_t)C * Hin * Win * 4, hold, &din)) || (rc = to_device(e, iy, (size_t)Hout * Ky * 4, hold, &diy)) ||
+        (rc = to_device(e, wy, (size_t)Hout * Ky * 4, hold, &dwy)) || (rc = to_device(e, ix, (size_t)Wout * Kx * 4, hold, &dix)) ||
+        (rc = to_device(e, wx, (size_t)Wout * Kx * 4, hold, &dwx))) return rc;
+    OutStage os;
+    if ((rc = out_device(e, out, (size_t)C * Hout * Wout * 4, hold, &os))) return rc;
+    Buf tmp(new DevBuf());
+    HIP_TRY(tmp->alloc((size_t)C * Hin * Wout * 4, false));
+    hipLaunchKernelGGL(resample_rows_kernel, grid1((size_t)C * Hin * Wout), dim3(256), 0, st, (const float*)din, (float*)tmp->p, C, Hin, Win, Wout, (const int*)dix, (const float*)dwx, Kx);
+    hipLaunchKernelGGL(resample_cols_kernel, grid1((size_t)C * Hout * Wout), dim3(256), 0, st, (const float*)tmp->p, (float*)os.dev, C, Hin, Hout, Wout, (const int*)diy, (const float*)dwy, Ky);
+    HIP_TRY(hipGetLastError());
+    if ((rc = out_finish(e, os))) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    return TD_OK;
+}
+
+int td_residual_plus(td_engine* e, const float* packed, const float* lowres_up, int Hp, int Wp, float res_mean, float res_std, float* out) {
+    DevGuard dg_(e->device);
+    if (!is_device_ptr(packed) || !is_device_ptr(lowres_up) || !is_device_ptr(out)) return fail(TD_ERR_ARG, "td_residual_plus: device buffers only");
+    hipLaunchKernelGGL(residual_plus_kernel, grid1((size_t)Hp * Wp), dim3(256), 0, e->stream, packed, lowres_up, out, Hp * Wp, res_mean, res_std);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return TD_OK;
+}
+
+int td_elev_finish(td_engine* e, const float* packed, const float* lowres_up, int Hp, int Wp, int oi, int oj, int h, int w, float res_mean, float res_std, float* out) {
+    DevGuard dg_(e->device);
+    if (!is_device_ptr(packed) || !is_device_ptr(lowres_up) || !is_device_ptr(out)) return fail(TD_ERR_ARG, "td_elev_finish: device buffers only");
+    if (oi < 0 || oj < 0 || oi + h > Hp || oj + w > Wp) return fail(TD_ERR_ARG, "td_elev_finish: crop outside the window");
+    hipLaunchKernelGGL(elev_finish_kernel, grid1((size_t)h * w), dim3(256), 0, e->stream, packed, lowres_up, out, Hp, Wp, oi, oj, h, w, res_mean, res_std);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
     return TD_OK;
 }

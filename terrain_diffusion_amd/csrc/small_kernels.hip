@@ -200,14 +200,17 @@ __global__ void unpack_output_kernel(const float* __restrict__ F, float* __restr
 // preconditioning (dpmsolver.py:226-229).  x, m1 planar fp32 [N][C][HW]; F NHWC fp32.
 template <typename T>
 __global__ void dpm_step_kernel(float* __restrict__ x, float* __restrict__ m1, const float* __restrict__ F, T* __restrict__ xin,
-                                int N, int C, int HW, int fstride, int cstride, SchedCoef k) {
+                                int N, int C, int HW, int fstride, int cstride, SchedCoef k, const float* __restrict__ Fg, float gscale,
+                                T* __restrict__ xin2) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)N * HW) return;
     int n = (int)(i / HW), p = (int)(i % HW);
     for (int c = 0; c < C; ++c) {
         size_t xi = ((size_t)n * C + c) * HW + p;
         float xs = x[xi];
-        float m0 = k.c_skip * xs + k.c_out * F[i * fstride + c];
+        float f = F[i * fstride + c];
+        if (Fg) { const float g = Fg[i * fstride + c]; f = g + gscale * (f - g); }  // autoguidance (sample_diffusion_base.py:107-110,155-160)
+        float m0 = k.c_skip * xs + k.c_out * f;
         float xn;
         if (k.order == 1) {
             xn = k.a * xs - k.b0 * m0;
@@ -217,7 +220,10 @@ __global__ void dpm_step_kernel(float* __restrict__ x, float* __restrict__ m1, c
         }
         x[xi] = xn;
         m1[xi] = m0;
-        if (!k.last) xin[i * cstride + c] = (T)(xn * k.c_in_next);
+        if (!k.last) {
+            xin[i * cstride + c] = (T)(xn * k.c_in_next);
+            if (xin2) xin2[i * cstride + c] = (T)(xn * k.c_in_next);  // the guide model's input buffer
+        }
     }
 }
 
@@ -399,8 +405,8 @@ template __global__ void prep_input_kernel<float>(const float*, float*, int, int
 template __global__ void prep_input_kernel<__bf16>(const float*, __bf16*, int, int, int, int, float, int);
 template __global__ void write_cond_img_kernel<float>(const float*, float*, int, int, int, int, int);
 template __global__ void write_cond_img_kernel<__bf16>(const float*, __bf16*, int, int, int, int, int);
-template __global__ void dpm_step_kernel<float>(float*, float*, const float*, float*, int, int, int, int, int, SchedCoef);
-template __global__ void dpm_step_kernel<__bf16>(float*, float*, const float*, __bf16*, int, int, int, int, int, SchedCoef);
+template __global__ void dpm_step_kernel<float>(float*, float*, const float*, float*, int, int, int, int, int, SchedCoef, const float*, float, float*);
+template __global__ void dpm_step_kernel<__bf16>(float*, float*, const float*, __bf16*, int, int, int, int, int, SchedCoef, const float*, float, __bf16*);
 template __global__ void consistency_pre_kernel<float>(const float*, const float*, float*, float*, int, int, int, int, float, float, float, int);
 template __global__ void consistency_pre_kernel<__bf16>(const float*, const float*, float*, __bf16*, int, int, int, int, float, float, float, int);
 

@@ -192,3 +192,71 @@ class InfiniteTensor:
 
     def clear_cache(self):
         self.tile_store.clear(self.tensor_id)
+
+
+class DeviceTileStore(MemoryTileStore):
+    """LRU cache of window outputs that stay in HBM (device tensors), bounded in bytes.  Same interface as MemoryTileStore; eviction is
+    safe for the same reason (every window is a pure function of its index and the seed: evict-and-recompute is bit-identical)."""
+
+    def __init__(self, cache_size_bytes=8 * 2 ** 30):
+        super().__init__(cache_size_bytes=cache_size_bytes)
+
+
+class DeviceWindowTensor(InfiniteTensor):
+    """InfiniteTensor whose windows live on the GPU and whose regions are assembled by the engine's blend kernel (K8, td_blend_windows).
+
+    Contract with the stage function: f(ctxs, *lists_of_arg_slices) -> device tensor (n, C, T, T) of RAW window outputs (not packed).
+    The tensor presents the reference's packed layout: shape (C+1, None, None), tensor[:, y0:y1, x0:x1] = (sum_w out_w * win, sum_w win)
+    over the windows intersecting the region, summed in ascending (row, col) window order by one launch of the deterministic gather
+    kernel -- the same arithmetic as summing the packed windows pack(out) = cat(out * win, win) of annotated_infinite_panorama.py:148-150.
+    Slices are returned as DEVICE tensors; nothing crosses to the host unless the caller asks (.cpu()).  Upstream tensors passed as `args`
+    are sliced the same way, so a chain coarse -> latent phases -> decoder never leaves HBM."""
+
+    def __init__(self, channels, f, tile, stride, engine, args=(), args_windows=(), tile_store=None, tensor_id=None, batch_size=None, offset=(0, 0)):
+        win = TensorWindow(size=(channels + 1, tile, tile), stride=(channels + 1, stride, stride), offset=(0,) + tuple(offset))
+        super().__init__((channels + 1, None, None), f, win, args=args, args_windows=args_windows,
+                         tile_store=tile_store if tile_store is not None else DeviceTileStore(), tensor_id=tensor_id, batch_size=batch_size)
+        self.channels, self.tile, self.stride_hw, self.engine = int(channels), int(tile), int(stride), engine
+        self.device = torch.device("cuda", engine.device_id)
+        self.windows_computed = 0
+
+    def _ensure(self, ctxs):
+        out, missing = {}, []
+        for c in ctxs:
+            t = self.tile_store.get((self.tensor_id, c))
+            if t is None:
+                missing.append(c)
+            else:
+                out[c] = t
+        bs = self.batch_size or len(missing) or 1
+        for b0 in range(0, len(missing), bs):
+            chunk = missing[b0:b0 + bs]
+            arg_lists = [[a[tuple(slice(l, h) for l, h in aw.bounds(c))] for c in chunk] for a, aw in zip(self.args, self.args_windows)]
+            res = self.f(list(chunk), *arg_lists)
+            assert res.is_cuda and tuple(res.shape) == (len(chunk), self.channels, self.tile, self.tile), (tuple(res.shape), res.device)
+            self.windows_computed += len(chunk)
+            for k, c in enumerate(chunk):
+                t = res[k].clone()   # own storage: the batch tensor can be freed while the window stays cached
+                self.tile_store.put((self.tensor_id, c), t)
+                out[c] = t
+        return out
+
+    def __getitem__(self, idx):
+        from .sampling import blend_windows
+        lo, hi, squeeze = self._normalize_slices(idx)
+        if (lo[0], hi[0]) != (0, self.channels + 1):
+            full = self[(slice(None), slice(lo[1], hi[1]), slice(lo[2], hi[2]))]
+            sub = full[lo[0]:hi[0]]
+            return sub.squeeze(0) if 0 in squeeze else sub
+        ctxs = sorted(self._windows_for(lo, hi))
+        tiles = self._ensure(ctxs)
+        rows = sorted({c[1] for c in ctxs})
+        cols = sorted({c[2] for c in ctxs})
+        oy, ox = self.output_window.offset[1], self.output_window.offset[2]
+        canvas = torch.empty((self.channels + 1, hi[1] - lo[1], hi[2] - lo[2]), dtype=torch.float32, device=self.device)
+        stack = torch.stack([tiles[c] for c in ctxs]).contiguous()
+        blend_windows(self.engine, canvas, stack, [(rows.index(c[1]), cols.index(c[2])) for c in ctxs],
+                      [r * self.stride_hw + oy - lo[1] for r in rows], [c * self.stride_hw + ox - lo[2] for c in cols], self.tile, accumulate=False)
+        for d in reversed([d for d in squeeze if d != 0]):
+            canvas = canvas.squeeze(d)
+        return canvas

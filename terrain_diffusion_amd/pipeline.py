@@ -29,7 +29,7 @@ LATENT_COND_STD = (21.72, 21.78, 10.40, 452.29, 738.09, 34.59, 0.47)
 
 def build_latent_stage(model, sigma_data=0.5, sigma_max=80.0, *, seed, cond_fn=None, coarse=None, histogram_raw=None,
                        cond_means=LATENT_COND_MEAN, cond_stds=LATENT_COND_STD, intermediate_ts=(math.atan(0.35 / 0.5),), T=2,
-                       onestep_latent=False, tile=64, channels=5, batch_size=16, tile_store=None, tensor_prefix="latents"):
+                       onestep_latent=False, tile=64, channels=5, batch_size=16, tile_store=None, tensor_prefix="latents", device_resident=False):
     """Returns the final-phase InfiniteTensor of shape (channels+1, None, None)  (world_pipeline.py:1133-1203).
 
     Conditioning source, one of
@@ -38,7 +38,9 @@ def build_latent_stage(model, sigma_data=0.5, sigma_max=80.0, *, seed, cond_fn=N
         ones mask and goes through process_latent_conditioning with seed_offset = i*65536 + j (world_pipeline.py:1080-1088);
       cond_fn(ctxs) -> (len(ctxs), cond_dim): a caller-supplied conditioning matrix for window indices ctxs = [(0, i, j), ...].
     T=2: one InfiniteTensor per trig-flow phase, blended between phases; T=1: all phases inside one window function
-    (world_pipeline.py:1149-1172).  onestep_latent stops after the first phase."""
+    (world_pipeline.py:1149-1172).  onestep_latent stops after the first phase.
+    device_resident=True: windows stay in HBM (DeviceWindowTensor / DeviceTileStore), regions are assembled by the engine's blend kernel and
+    slices are device tensors; False: host tensors and a host tile store exactly as the reference keeps them (world_pipeline.py:1129)."""
     from .sampling import process_latent_conditioning
     if (cond_fn is None) == (coarse is None):
         raise ValueError("give exactly one of cond_fn= or coarse=")
@@ -58,11 +60,12 @@ def build_latent_stage(model, sigma_data=0.5, sigma_max=80.0, *, seed, cond_fn=N
         rows = []
         for ctx, c in zip(ctxs, conds):
             c = torch.as_tensor(c, dtype=torch.float32)
-            cimg = torch.cat([c[:-1] / c[-1:], torch.ones(1, 4, 4)], dim=0)[None]                     # world_pipeline.py:1080-1083
+            cimg = torch.cat([c[:-1] / c[-1:], torch.ones(1, 4, 4, device=c.device)], dim=0)[None]    # world_pipeline.py:1080-1083
             rows.append(process_latent_conditioning(cimg, hist, cond_means, cond_stds, 0.0, seed=seed, seed_offset=ctx[1] * 65536 + ctx[2]))
         return torch.cat(rows, dim=0)
 
-    def infer(phase, t, ctxs, prevs, conds):
+    def infer_raw(phase, t, ctxs, prevs, conds):
+        """one trig-flow phase on a batch of windows -> (n, channels, tile, tile) on the device, divided by sigma_data (world_pipeline.py:1129)"""
         n = len(ctxs)
         origins = [(c[1] * stride, c[2] * stride) for c in ctxs]
         z = _noise.gaussian_noise_patches(seed + 5819 + phase, origins, tile, tile, channels=channels, tile_h=tile, tile_w=tile, device=dev)
@@ -72,8 +75,32 @@ def build_latent_stage(model, sigma_data=0.5, sigma_max=80.0, *, seed, cond_fn=N
         cond = conditioning(ctxs, conds).to(dev).contiguous()
         out = torch.empty_like(z)
         check(lib().td_sample_consistency(model._h, n, tile, tile, float(t), float(sigma_data), ptr(sample), ptr(z), ptr(cond), ptr(out)))
-        out = out.cpu() / sigma_data  # world_pipeline.py:1129
+        return out / sigma_data
+
+    def infer(phase, t, ctxs, prevs, conds):
+        out = infer_raw(phase, t, ctxs, prevs, conds).cpu()  # world_pipeline.py:1129: the reference keeps window outputs on the host
         return [torch.cat([o * w[None], w[None]], dim=0) for o in out]
+
+    if device_resident:
+        from .infinite_tensor import DeviceWindowTensor
+        cw = cwin if coarse is not None else None
+        dsrc, dwin = ((coarse,), (cw,)) if coarse is not None else ((), ())
+        mk = lambda f, args, wins, tid: DeviceWindowTensor(channels, f, tile, stride, model.engine, args=args, args_windows=wins, tile_store=tile_store,
+                                                            tensor_id=tid, batch_size=batch_size)
+        if T == 1:
+            def f_t1d(ctxs, conds=None):
+                outs = None
+                for k, t in enumerate(ts):   # later phases read the window's own previous output (no blend): pack it the way a slice would arrive
+                    prevs = None if outs is None else [torch.cat([o * w.to(dev)[None], w.to(dev)[None]], dim=0) for o in outs]
+                    outs = infer_raw(k, t, ctxs, prevs, conds)
+                return outs
+            lat = mk(f_t1d, dsrc, dwin, f"{tensor_prefix}_T1")
+        else:
+            lat = mk(lambda ctxs, conds=None: infer_raw(0, ts[0], ctxs, None, conds), dsrc, dwin, f"{tensor_prefix}_phase0")
+            for k, t in enumerate(ts[1:], 1):
+                lat = mk(lambda ctxs, prevs, conds=None, k=k, t=t: infer_raw(k, t, ctxs, prevs, conds), (lat,) + dsrc, (win,) + dwin, f"{tensor_prefix}_phase{k}")
+        lat.infer = infer
+        return lat
 
     src_args, src_wins = ((coarse,), (cwin,)) if coarse is not None else ((), ())
     shape = (channels + 1, None, None)
@@ -116,7 +143,7 @@ def pool_coarse_conditioning(img, n, elev_mode="avg", p5_mode="avg"):
 
 def build_coarse_stage(model, scheduler, *, seed, cond_map_fn, coarse_means, coarse_stds, cond_snr, coarse_pooling=1,
                        elev_coarse_pool_mode="avg", p5_coarse_pool_mode="avg", steps=20, batch_size=16, tile_store=None,
-                       tensor_id="base_coarse_map"):
+                       tensor_id="base_coarse_map", device_resident=False):
     """InfiniteTensor (7, None, None) of packed coarse windows (world_pipeline.py:961-992).
     model: coarse EDMUnet2D (11 -> 6 channels, five "float" conditional inputs); cond_map_fn(i1, i2, j1, j2) -> (5, 64, 64) is the
     reference's `_conditioning_model_input` (synthetic map, channels [0,2,3,4,5] of the coarse statistics)."""
@@ -134,7 +161,8 @@ def build_coarse_stage(model, scheduler, *, seed, cond_map_fn, coarse_means, coa
     cond_vals = torch.log(torch.tan(t_cond) / 8.0)
     tc = t_cond.view(1, -1, 1, 1).to(dev)
 
-    def f(ctxs):
+    def f_raw(ctxs):
+        """(n, 6, T/pool, T/pool) de-normalised, pooled coarse windows on the device"""
         n = len(ctxs)
         origins = [(c[1] * (S // pool) * pool, c[2] * (S // pool) * pool) for c in ctxs]
         smap = torch.stack([(torch.as_tensor(cond_map_fn(i1, i1 + T, j1, j1 + T), dtype=torch.float32) - means[sel, None, None]) / stds[sel, None, None]
@@ -145,22 +173,25 @@ def build_coarse_stage(model, scheduler, *, seed, cond_map_fn, coarse_means, coa
         x = _noise.gaussian_noise_patches(seed + 1, origins, T, T, channels=6, tile_h=T, tile_w=T, device=dev) * float(scheduler.sigmas[0])
         cond = model.cond_rows([v.view(1).expand(n) for v in cond_vals], n, dev)
         sample_tiles_edm(model, scheduler, x, cond, steps, cond_img=cond_img)
-        x = x.cpu().float() / sigma_data                                                    # world_pipeline.py:950-952
-        x = x * stds.view(1, -1, 1, 1) + means.view(1, -1, 1, 1)
+        x = x.float() / sigma_data                                                          # world_pipeline.py:950-952
+        x = x * stds.view(1, -1, 1, 1).to(dev) + means.view(1, -1, 1, 1).to(dev)
         x[:, 1] = x[:, 0] - x[:, 1]
-        outs = []
-        for k in range(n):
-            o = pool_coarse_conditioning(x[k], pool, elev_coarse_pool_mode, p5_coarse_pool_mode)
-            outs.append(torch.cat([o * w[None], w[None]], dim=0))
-        return outs
+        return torch.stack([pool_coarse_conditioning(x[k], pool, elev_coarse_pool_mode, p5_coarse_pool_mode) for k in range(n)])
 
+    def f(ctxs):
+        outs = f_raw(ctxs).cpu()                                                            # the reference's `.cpu().float()` (:951)
+        return [torch.cat([o * w[None], w[None]], dim=0) for o in outs]
+
+    if device_resident:
+        from .infinite_tensor import DeviceWindowTensor
+        return DeviceWindowTensor(6, f_raw, T // pool, S // pool, model.engine, tile_store=tile_store, tensor_id=tensor_id, batch_size=batch_size)
     win = TensorWindow(size=(7, T // pool, T // pool), stride=(7, S // pool, S // pool))
     return InfiniteTensor((7, None, None), f, win, tile_store=tile_store if tile_store is not None else MemoryTileStore(), tensor_id=tensor_id,
                           batch_size=batch_size)
 
 
 def build_decoder_stage(model, latents, *, seed, sigma_data=0.5, sigma_max=80.0, tile_size=512, tile_stride=384, latent_compression=8,
-                        extra_ts=(), batch_size=4, tile_store=None, tensor_id="init_residual_map"):
+                        extra_ts=(), batch_size=4, tile_store=None, tensor_id="init_residual_map", device_resident=False):
     """InfiniteTensor (2, None, None) of packed decoder windows (world_pipeline.py:1244-1270) over the latent stage's tensor `latents`
     ((6, None, None): 5 latent channels + weight).  One trig-flow step at t = atan(sigma_max / sigma_data) (+ `extra_ts`)."""
     from .sampling import consistency_step
@@ -169,7 +200,7 @@ def build_decoder_stage(model, latents, *, seed, sigma_data=0.5, sigma_max=80.0,
     w = _linear_weight_window(T, dev)[0, 0].cpu()
     t_list = (float(torch.atan(torch.tensor(sigma_max, dtype=torch.float32) / sigma_data)),) + tuple(float(torch.as_tensor(t, dtype=torch.float32)) for t in extra_ts)
 
-    def f(ctxs, lats):
+    def f_raw(ctxs, lats):
         n = len(ctxs)
         origins = [(c[1] * S, c[2] * S) for c in ctxs]
         lat = torch.stack([(torch.as_tensor(p)[:-1] / torch.as_tensor(p)[-1:])[:4] for p in lats]).to(dev, dtype=torch.float32)   # :1223
@@ -178,10 +209,17 @@ def build_decoder_stage(model, latents, *, seed, sigma_data=0.5, sigma_max=80.0,
         for i, t in enumerate(t_list):
             z = _noise.gaussian_noise_patches(seed + 5819 + i, origins, T, T, channels=1, tile_h=T, tile_w=T, device=dev)
             sample = consistency_step(model, t, sigma_data, sample, z, cond=None, cond_img=up)
-        out = sample.cpu().float() / sigma_data
+        return sample.float() / sigma_data
+
+    def f(ctxs, lats):
+        out = f_raw(ctxs, lats).cpu()                                                       # world_pipeline.py:1241
         return [torch.cat([o * w[None], w[None]], dim=0) for o in out]
 
     owin = TensorWindow(size=(2, T, T), stride=(2, S, S))
     iwin = TensorWindow(size=(6, T // lc, T // lc), stride=(6, S // lc, S // lc))
+    if device_resident:
+        from .infinite_tensor import DeviceWindowTensor
+        return DeviceWindowTensor(1, f_raw, T, S, model.engine, args=(latents,), args_windows=(iwin,), tile_store=tile_store, tensor_id=tensor_id,
+                                  batch_size=batch_size)
     return InfiniteTensor((2, None, None), f, owin, args=(latents,), args_windows=(iwin,),
                           tile_store=tile_store if tile_store is not None else MemoryTileStore(), tensor_id=tensor_id, batch_size=batch_size)

@@ -57,24 +57,27 @@ def _process_cond_img(cond_img, histogram_raw, cond_means, cond_stds, noise_leve
 
 
 def process_latent_conditioning(cond_img, histogram_raw, cond_means, cond_stds, noise_level=0.0, *, seed, seed_offset=0):
-    """WorldPipeline._process_latent_conditioning (world_pipeline.py:1018-1050) on the host: (B,7,4,4) -> (B,58).
+    """WorldPipeline._process_latent_conditioning (world_pipeline.py:1018-1050): (B,7,4,4) -> (B,58), on whatever device cond_img lives
+    (the device-resident pipeline hands over HBM tensors; 58 floats per window never need the host).
     Keeps the reference's behaviour to the letter, including its batch-dimension NaN fill: every NaN of sample 0 becomes cond_means[0]
     and of sample 1 cond_means[1] (after normalisation); NaN climate means of further samples are drawn from the portable RNG seeded
     seed + 9999 + seed_offset (the engine's generator: same stream as portable_rng.standard_normal)."""
     from .noise import standard_normal
+    cond_img = torch.as_tensor(cond_img, dtype=torch.float32)
+    dev = cond_img.device
     cond_means = torch.as_tensor(cond_means, dtype=torch.float32)
     cond_stds = torch.as_tensor(cond_stds, dtype=torch.float32)
-    cond_img = (torch.as_tensor(cond_img, dtype=torch.float32).cpu() - cond_means.view(1, -1, 1, 1)) / cond_stds.view(1, -1, 1, 1)
+    cond_img = (cond_img - cond_means.view(1, -1, 1, 1).to(dev)) / cond_stds.view(1, -1, 1, 1).to(dev)
     cond_img[0:1] = cond_img[0:1].nan_to_num(float(cond_means[0]))
     cond_img[1:2] = cond_img[1:2].nan_to_num(float(cond_means[1]))
     clim = cond_img[:, 2:6, 1:3, 1:3].mean(dim=(2, 3))
     nan_mask = torch.isnan(clim)
     cnt = int(nan_mask.sum())
     if cnt > 0:
-        clim[nan_mask] = torch.from_numpy(standard_normal(seed + 9999 + seed_offset, (cnt,), dtype=np.float32))
+        clim[nan_mask] = torch.from_numpy(standard_normal(seed + 9999 + seed_offset, (cnt,), dtype=np.float32)).to(dev)
     B = cond_img.shape[0]
-    nl = (torch.as_tensor(noise_level, dtype=torch.float32) - 0.5) * np.sqrt(12)
-    hist = torch.as_tensor(histogram_raw, dtype=torch.float32)
+    nl = ((torch.as_tensor(noise_level, dtype=torch.float32) - 0.5) * np.sqrt(12)).to(dev)
+    hist = torch.as_tensor(histogram_raw, dtype=torch.float32).to(dev)
     parts = [cond_img[:, 0:1].flatten(1), cond_img[:, 1:2].flatten(1), clim.flatten(1), cond_img[:, 6:7].flatten(1),
              hist.view(-1, hist.shape[-1]).expand(B, -1), nl.view(-1, 1).expand(B, 1)]
     n = len(parts)
@@ -109,7 +112,7 @@ def blend_normalize(engine, canvas, scale=1.0):
 
 
 @torch.no_grad()
-def sample_tiles_edm(model, scheduler, x, cond, steps, cond_img=None):
+def sample_tiles_edm(model, scheduler, x, cond, steps, cond_img=None, guide_model=None, guidance_scale=1.0):
     """Runs `steps` DPM-Solver++ steps on a batch of independent tiles (device tensor x: [n,C,H,W], scaled noise). In place.
     cond_img: optional [n,Cc,H,W] conditioning-image channels concatenated after the sample channels in the model input
     (coarse stage: world_pipeline.py:946 `torch.cat([scaled_in, cond_img], dim=1)`)."""
@@ -118,6 +121,11 @@ def sample_tiles_edm(model, scheduler, x, cond, steps, cond_img=None):
     model.engine.set_option("solver_order", int(getattr(scheduler.config, "solver_order", 2)))
     n, _, H, W = x.shape
     cimg = 0 if cond_img is None else cond_img.shape[1]
+    if guide_model is not None and guidance_scale != 1.0:   # autoguidance (sample_diffusion_base.py:105-110)
+        if cond_img is not None:
+            raise NotImplementedError("autoguidance with conditioning-image channels")
+        check(lib().td_sample_edm_guided(model._h, guide_model._h, float(guidance_scale), n, H, W, steps, ptr(sig), float(scheduler.config.sigma_data), ptr(cond), ptr(x)))
+        return x
     check(lib().td_sample_edm_img(model._h, n, H, W, steps, ptr(sig), float(scheduler.config.sigma_data), ptr(cond), ptr(cond_img), cimg, ptr(x)))
     return x
 
@@ -142,8 +150,6 @@ def sample_base_diffusion(model, scheduler, shape, cond_inputs, *, cond_means, c
     `tiles`: optional subset of (ic, jc) window indices to run (multi-GPU sharding); `return_canvas` returns the
     un-normalised (C+1,H,W) accumulator instead of output/weights/sigma_data; `return_windows` additionally returns the
     pre-blend window outputs [(ic, jc)] -> (C, T, T) device tensors (parity tests look at windows before the blend mixes them)."""
-    if guide_model is not None and guidance_scale != 1.0:
-        raise NotImplementedError("autoguidance is not on the accelerated path yet")
     if weight_window_fn is not None:
         raise NotImplementedError("custom weight windows")
     B, C_, H, W = shape
@@ -178,7 +184,7 @@ def sample_base_diffusion(model, scheduler, shape, cond_inputs, *, cond_means, c
         nth, ntw = max(64, th), max(64, tw)
         x = _noise.gaussian_noise_patches(noise_seed, origins, th, tw, channels=C_, tile_h=nth, tile_w=ntw, scale=sigma0, device=dev)
         cond = _tile_conditioning(cond_inputs, chunk, histogram_raw, cond_means, cond_stds, noise_level).to(dev).contiguous()
-        sample_tiles_edm(model, scheduler, x, cond, steps)
+        sample_tiles_edm(model, scheduler, x, cond, steps, guide_model=guide_model, guidance_scale=guidance_scale)
         if tile_size is None:
             return x
         if return_windows:

@@ -306,6 +306,48 @@ def gen_sampling():
     save("sampling", **out)
 
 
+def gen_guided():
+    """autoguidance (sample_diffusion_base.py:105-110,155-160): main + guide model (different widths, like 192 vs 128 in the 30m configs)."""
+    from terrain_diffusion.scheduler.dpmsolver import EDMDPMSolverMultistepScheduler
+    from terrain_diffusion.training.evaluation import sample_diffusion_base as sdb_mod
+    from oracle import tiling
+    from oracle.unet import tiny_config, synth_state_dict
+    cfg_m, cfg_g = tiny_config(128, 1), tiny_config(64, 1)
+    m = _ref_model(cfg_m, synth_state_dict(cfg_m, seed=81))
+    g = _ref_model(cfg_g, synth_state_dict(cfg_g, seed=82))
+    sch = EDMDPMSolverMultistepScheduler(sigma_min=0.002, sigma_max=80.0, sigma_data=0.5)
+    real_randn = torch.randn
+    out = {}
+    for key, (H, W, steps, tile, scale) in {"guided_grid3_steps6_s2": (32, 32, 6, 16, 2.0), "guided_ragged_24x40_steps5_s1p5": (24, 40, 5, 16, 1.5)}.items():
+        torch.randn = lambda shape, generator=None, device=None, dtype=None: tiling.initial_noise_field(42 + 5819, H, W, 5)
+        try:
+            cond = tiling.synthetic_cond_grid(len(tiling.tile_starts(H, tile, tile // 2)), len(tiling.tile_starts(W, tile, tile // 2)))
+            out[key] = sdb_mod.sample_base_diffusion(m, sch, (1, 5, H, W), cond, cond_means=torch.zeros(7), cond_stds=torch.ones(7), noise_level=torch.tensor(0.0),
+                                                     histogram_raw=torch.zeros(1, 5), steps=steps, tile_size=tile, guide_model=g, guidance_scale=scale).numpy()
+        finally:
+            torch.randn = real_randn
+    save("guided", **out)
+
+
+def gen_compose():
+    """postprocessing.local_baseline_temperature_torch and the Laplacian pyramid's pure helper pad_linear_extrapolation, run from the
+    reference's own source (AST-extracted: the modules import matplotlib / torchvision, which are absent here)."""
+    import torch.nn.functional as F
+    from oracle import rng
+    ns = {"torch": torch, "F": F, "np": np}
+    extract_functions(os.path.join(REF, "terrain_diffusion", "inference", "postprocessing.py"), ["local_baseline_temperature_torch"], ns)
+    extract_functions(os.path.join(REF, "terrain_diffusion", "data", "laplacian_encoder.py"), ["pad_linear_extrapolation"], ns)
+    T = torch.from_numpy(rng.standard_normal(501, (40, 52))) * 8 + 12
+    e = torch.from_numpy(rng.standard_normal(502, (40, 52))) * 600 + 150
+    out = {"lbt_T": T.numpy(), "lbt_e": e.numpy()}
+    for win, thr in ((15, 0.02), (3, 0.3)):
+        ts, beta = ns["local_baseline_temperature_torch"](T, e, win=win, fallback_threshold=thr)
+        out[f"lbt_sea_w{win}"], out[f"lbt_beta_w{win}"] = ts.numpy()[0], beta.numpy()[0]
+    x = torch.from_numpy(rng.standard_normal(503, (2, 7, 9)))
+    out["ple_in"], out["ple_out"] = x.numpy(), ns["pad_linear_extrapolation"](x).numpy()
+    save("compose", **out)
+
+
 def gen_stages():
     """EDMUnet2D in its other two pipeline roles: coarse model (5 'float' conditional inputs through MPFourier,
     11 -> 6 channels) and decoder (no conditional inputs, 5 -> 1 channels), full-size configs at 64x64 input."""
@@ -433,7 +475,7 @@ def gen_latent_glue():
     save("latent_glue", **out)
 
 
-ALL = dict(latent_glue=gen_latent_glue, stage_glue=gen_stage_glue, stages=gen_stages, rng=gen_rng, geometry=gen_geometry, schedule=gen_schedule, unet=gen_unet, sampling=gen_sampling)
+ALL = dict(compose=gen_compose, guided=gen_guided, latent_glue=gen_latent_glue, stage_glue=gen_stage_glue, stages=gen_stages, rng=gen_rng, geometry=gen_geometry, schedule=gen_schedule, unet=gen_unet, sampling=gen_sampling)
 
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden generation needs the reference checkout"

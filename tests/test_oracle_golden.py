@@ -271,3 +271,16 @@ def test_latent_glue_oracle_matches_reference(golden):
     assert rel_rms(torch.stack(p0).numpy(), g["latent_phase0"]) < 5e-6
     p1 = stages.latent_inference(m, ctxs, list(torch.from_numpy(g["latent_phase0"])), conds, torch.arctan(torch.tensor(0.35) / 0.5), seed_offset=5820, **kw)
     assert rel_rms(torch.stack(p1).numpy(), g["latent_phase1_from_phase0_windows"]) < 5e-6
+
+
+def test_autoguidance_oracle_matches_reference(golden):
+    """oracle tiled sampler with a guide model (F = F_g + s (F_m - F_g), sample_diffusion_base.py:155-160) against the reference's own
+    sample_base_diffusion(guide_model=..., guidance_scale=...) outputs (tests/golden/make_golden.py::gen_guided)."""
+    from oracle import tiling
+    g = golden("guided")
+    cfg_m, cfg_g = tiny_config(128, 1), tiny_config(64, 1)
+    m, gm = OracleUnet(cfg_m, synth_state_dict(cfg_m, seed=81)), OracleUnet(cfg_g, synth_state_dict(cfg_g, seed=82))
+    for key, (H, W, steps, scale) in {"guided_grid3_steps6_s2": (32, 32, 6, 2.0), "guided_ragged_24x40_steps5_s1p5": (24, 40, 5, 1.5)}.items():
+        cond = tiling.synthetic_cond_grid(len(tiling.tile_starts(H, 16, 8)), len(tiling.tile_starts(W, 16, 8)))
+        y = tiling.sample_base_diffusion_tiled(m, (1, 5, H, W), cond, steps=steps, tile_size=16, guide_model=gm, guidance_scale=scale)
+        assert rel_rms(y.numpy(), g[key]) < 1e-5, key
