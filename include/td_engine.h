@@ -164,6 +164,13 @@ int td_residual_plus(td_engine* e, const float* packed, const float* lowres_up, 
 int td_elev_finish(td_engine* e, const float* packed, const float* lowres_up, int Hp, int Wp, int oi, int oj, int h, int w, float res_mean,
                    float res_std, float* out);
 
+/* ---- synthetic conditioning map (terrain_diffusion/inference/synthetic_map.py:182-236, perlin_transform.py:41-45) ----
+ * One channel of the coarse conditioning source over rows [i1, i1+rows) x cols [j1, j1+cols): gradient-noise FBm (x = row, y = col, scaled by
+ * `frequency`; `octaves` octaves, lacunarity, gain; integer seed) pushed through the piecewise-linear quantile transfer src -> dst (n_quantiles
+ * ascending knots each, ends clamped).  The generator has FastNoiseLite's structure but its own gradient set: values are parity-unpinned. */
+int td_perlin_map(td_engine* e, int rows, int cols, int i1, int j1, int seed, float frequency, int octaves, float lacunarity, float gain,
+                  const float* src_quantiles, const float* dst_quantiles, int n_quantiles, float* out);
+
 #ifdef __cplusplus
 }
 #endif

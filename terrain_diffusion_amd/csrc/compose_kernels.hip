@@ -60,3 +60,57 @@ __global__ void residual_plus_kernel(const float* __restrict__ packed, const flo
 }
 
 }  // namespace td
+
+// ---- synthetic conditioning map: gradient-noise FBm with the structure of FastNoiseLite's Perlin / FBm path that
+// terrain_diffusion/inference/synthetic_map.py:182-236 drives (frequency, octaves, lacunarity 2, gain 0.5, one integer seed per channel),
+// followed by the 64-knot quantile transfer of perlin_transform.py:41-45 (np.interp with clamped ends).  pyfastnoiselite is not available in
+// the build container and its 128-entry gradient table is not reproduced here (unit vectors at equally spaced angles instead), so the noise
+// VALUES are this package's own: parity unpinned; the structure, parameters and the transfer are the reference's.
+namespace td {
+
+__device__ __forceinline__ float pn_grad(int seed, int xp, int yp, float xd, float yd) {
+    int h = seed ^ xp ^ yp;
+    h *= 0x27d4eb2d;
+    h ^= h >> 15;
+    const float a = (float)(h & 127) * (6.283185307179586f / 128.f) + (3.141592653589793f / 128.f);
+    return xd * __cosf(a) + yd * __sinf(a);
+}
+
+__device__ __forceinline__ float pn_single(int seed, float x, float y) {
+    const float fx = floorf(x), fy = floorf(y);
+    const float xd0 = x - fx, yd0 = y - fy, xd1 = xd0 - 1.f, yd1 = yd0 - 1.f;
+    const float xs = xd0 * xd0 * xd0 * (xd0 * (xd0 * 6.f - 15.f) + 10.f), ys = yd0 * yd0 * yd0 * (yd0 * (yd0 * 6.f - 15.f) + 10.f);
+    const int x0 = (int)fx * 501125321, y0 = (int)fy * 1136930381, x1 = x0 + 501125321, y1 = y0 + 1136930381;
+    const float a = pn_grad(seed, x0, y0, xd0, yd0), b = pn_grad(seed, x1, y0, xd1, yd0);
+    const float c = pn_grad(seed, x0, y1, xd0, yd1), d = pn_grad(seed, x1, y1, xd1, yd1);
+    const float xf0 = a + xs * (b - a), xf1 = c + xs * (d - c);
+    return (xf0 + ys * (xf1 - xf0)) * 1.4247691104677813f;
+}
+
+// out[r][c] = transfer(fbm(x = i1 + r, y = j1 + c)) for one channel; knots: 64 source / target quantiles (ascending)
+__global__ void perlin_map_kernel(float* __restrict__ out, int rows, int cols, int i1, int j1, int seed, float frequency, int octaves, float lacunarity, float gain,
+                                  const float* __restrict__ src_q, const float* __restrict__ dst_q, int nq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    float x = (float)(i1 + i / cols) * frequency, y = (float)(j1 + i % cols) * frequency;
+    float bound = 1.f, a_ = fabsf(gain);
+    for (int o = 1; o < octaves; ++o) { bound += a_; a_ *= fabsf(gain); }
+    float amp = 1.f / bound, sum = 0.f;
+    int s = seed;
+    for (int o = 0; o < octaves; ++o) {
+        sum += pn_single(s++, x, y) * amp;
+        x *= lacunarity; y *= lacunarity; amp *= gain;
+    }
+    // np.interp(sum, src_q, dst_q, left=dst_q[0], right=dst_q[-1])
+    float v;
+    if (sum <= src_q[0]) v = dst_q[0];
+    else if (sum >= src_q[nq - 1]) v = dst_q[nq - 1];
+    else {
+        int lo = 0, hi = nq - 1;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (src_q[mid] <= sum) lo = mid; else hi = mid; }
+        v = dst_q[lo] + (sum - src_q[lo]) * ((dst_q[hi] - dst_q[lo]) / (src_q[hi] - src_q[lo]));
+    }
+    out[i] = v;
+}
+
+}  // namespace td

@@ -1468,4 +1468,23 @@ int td_elev_finish(td_engine* e, const float* packed, const float* lowres_up, in
     return TD_OK;
 }
 
+// ---- synthetic conditioning map channel
+int td_perlin_map(td_engine* e, int rows, int cols, int i1, int j1, int seed, float frequency, int octaves, float lacunarity, float gain,
+                  const float* src_quantiles, const float* dst_quantiles, int n_quantiles, float* out) {
+    DevGuard dg_(e->device);
+    if (rows < 1 || cols < 1 || octaves < 1 || octaves > 16 || n_quantiles < 2) return fail(TD_ERR_ARG, "td_perlin_map: bad arguments");
+    std::vector<Buf> hold;
+    const void *ds, *dd;
+    int rc;
+    if ((rc = to_device(e, src_quantiles, (size_t)n_quantiles * 4, hold, &ds)) || (rc = to_device(e, dst_quantiles, (size_t)n_quantiles * 4, hold, &dd))) return rc;
+    OutStage os;
+    if ((rc = out_device(e, out, (size_t)rows * cols * 4, hold, &os))) return rc;
+    hipLaunchKernelGGL(perlin_map_kernel, grid1((size_t)rows * cols), dim3(256), 0, e->stream, (float*)os.dev, rows, cols, i1, j1, seed, frequency, octaves, lacunarity, gain,
+                       (const float*)ds, (const float*)dd, n_quantiles);
+    HIP_TRY(hipGetLastError());
+    if ((rc = out_finish(e, os))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return TD_OK;
+}
+
 }  // extern "C"

@@ -86,15 +86,45 @@ class MemoryTileStore:
 
 
 class HDF5TileStore(MemoryTileStore):
-    """Persistent world cache of the reference (world_pipeline.py:671-674).  h5py is not available in this environment; the
-    persistent format is listed as a "next" row in SURVEY.md §8f-3."""
+    """Persistent world cache of the reference (world_pipeline.py:671-674: infinite_tensor.HDF5TileStore).  With h5py importable the records go
+    to an HDF5 file (one dataset per (tensor_id, window index), the WORLD_PIPELINE_PARAMS attribute on the file); h5py is not installed in this
+    environment, where terrain_diffusion_amd.wire.FileTileStore offers the same persistence in a directory of .npy records."""
 
     def __init__(self, path, mode="a", compression="gzip", compression_opts=4, cache_size_tiles=100):
         try:
-            import h5py  # noqa: F401
+            import h5py
         except ImportError as e:
-            raise ImportError("HDF5TileStore needs h5py, which is not installed here; use MemoryTileStore") from e
-        raise NotImplementedError("HDF5 persistence is a 'next' row (SURVEY.md §8f-3)")
+            raise ImportError("HDF5TileStore needs h5py, which is not installed here; use terrain_diffusion_amd.wire.FileTileStore (same records, "
+                              ".npy directory) or MemoryTileStore") from e
+        super().__init__(cache_size_bytes=None)
+        self._h5 = h5py.File(path, mode)
+        self._kw = dict(compression=compression, compression_opts=compression_opts) if compression else {}
+        self.cache_size_tiles = cache_size_tiles
+
+    @staticmethod
+    def _name(key):
+        return str(key[0]) + "/" + "_".join(str(c) for c in key[1])
+
+    def get(self, key):
+        t = super().get(key)
+        if t is None and self._name(key) in self._h5:
+            t = torch.from_numpy(self._h5[self._name(key)][...])
+            super().put(key, t)
+        return t
+
+    def put(self, key, t):
+        t = torch.as_tensor(t).detach().cpu()
+        n = self._name(key)
+        if n in self._h5:
+            del self._h5[n]
+        self._h5.create_dataset(n, data=t.numpy(), **self._kw)
+        super().put(key, t)
+        while len(self._d) > self.cache_size_tiles:
+            self._d.popitem(last=False)
+
+    def close(self):
+        self._h5.close()
+        MemoryTileStore.clear(self)
 
 
 class InfiniteTensor:

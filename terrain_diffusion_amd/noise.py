@@ -18,6 +18,22 @@ def _tile_seed(base_seed: int, ty: int, tx: int) -> int:
     return int(lib().td_tile_seed(int(base_seed) & M64, int(ty), int(tx)))
 
 
+def next_seed(seed=None):
+    """portable_rng.py:31-42: a new 64-bit seed from a parent seed, or from the clock when seed is None / 0.  Host integers only: two steps
+    of the module's LCG (s <- s * 6364136223846793005 + 1442695040888963407 mod 2^64), each giving one 32-bit XSH-RR word of the NEW state."""
+    state = (int(seed) & M64) if seed is not None else 0
+    if state == 0:
+        import time
+        state = int(time.perf_counter_ns()) & M64
+    words = []
+    for _ in range(2):
+        state = (state * 6364136223846793005 + 1442695040888963407) & M64
+        x = (((state >> 18) ^ state) >> 27) & 0xFFFFFFFF
+        rot = state >> 59
+        words.append(((x >> rot) | (x << ((32 - rot) & 31))) & 0xFFFFFFFF)
+    return int(((words[1] << 32) | words[0]) & M64)
+
+
 def standard_normal(seed, size, dtype=np.float32, device="cuda", as_torch=False):
     shape = (size,) if isinstance(size, int) else tuple(size)
     n = int(np.prod(shape)) if shape else 1

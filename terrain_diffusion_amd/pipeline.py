@@ -165,8 +165,8 @@ def build_coarse_stage(model, scheduler, *, seed, cond_map_fn, coarse_means, coa
         """(n, 6, T/pool, T/pool) de-normalised, pooled coarse windows on the device"""
         n = len(ctxs)
         origins = [(c[1] * (S // pool) * pool, c[2] * (S // pool) * pool) for c in ctxs]
-        smap = torch.stack([(torch.as_tensor(cond_map_fn(i1, i1 + T, j1, j1 + T), dtype=torch.float32) - means[sel, None, None]) / stds[sel, None, None]
-                            for i1, j1 in origins]).to(dev)
+        m5, s5 = means[sel, None, None].to(dev), stds[sel, None, None].to(dev)
+        smap = torch.stack([(torch.as_tensor(cond_map_fn(i1, i1 + T, j1, j1 + T), dtype=torch.float32).to(dev) - m5) / s5 for i1, j1 in origins])
         cnoise = _noise.gaussian_noise_patches(seed, origins, T, T, channels=5, tile_h=T, tile_w=T, device=dev)
         cond_img = (torch.cos(tc) * smap + torch.sin(tc) * cnoise).contiguous()
         scheduler.set_timesteps(steps)
