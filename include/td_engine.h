@@ -27,7 +27,7 @@ typedef struct td_engine td_engine;
 typedef struct td_unet td_unet;
 
 enum { TD_OK = 0, TD_ERR_ARG = -1, TD_ERR_HIP = -2, TD_ERR_STATE = -3, TD_ERR_UNSUPPORTED = -4 };
-enum { TD_DTYPE_F32 = 0, TD_DTYPE_BF16 = 1 };
+enum { TD_DTYPE_F32 = 0, TD_DTYPE_BF16 = 1, TD_DTYPE_F16 = 2 };  /* storage type inside the engine; accumulation is always fp32 */
 
 /* EDMUnet2D constructor arguments that shape the inference graph
  * (terrain_diffusion/models/edm_unet.py:17-37). */

@@ -28,13 +28,37 @@ namespace td {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16_ __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 16-bit storage types of the engine: bf16 (default) and fp16 (WorldPipeline dtype='fp16', world_pipeline.py:365-370).  Same kernels, the
+// element type only selects the vector typedefs and the MFMA opcode (v_mfma_f32_{32x32x16,16x16x32}_{bf16,f16}); accumulation is fp32 in both.
+template <typename T> struct Half;
+template <> struct Half<__bf16> {
+    typedef bf16x8 x8; typedef bf16x4 x4;
+    static __device__ __forceinline__ f32x16_ mfma32(x8 a, x8 b, f32x16_ c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Half<_Float16> {
+    typedef f16x8 x8; typedef f16x4 x4;
+    static __device__ __forceinline__ f32x16_ mfma32(x8 a, x8 b, f32x16_ c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native 16-byte register piece (HIP's u32x4 struct defeats SROA -> scratch)
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int CHUNK = 32, PER16 = 4;
     static __device__ __forceinline__ float silu(float x) { return x / (1.f + expf(-x)) * (1.f / 0.596f); }
+};
+template <> struct Elem<_Float16> {
+    static constexpr int CHUNK = 64, PER16 = 8;
+    static __device__ __forceinline__ float silu(float x) {
+        return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)) * (1.f / 0.596f);
+    }
 };
 template <> struct Elem<__bf16> {
     static constexpr int CHUNK = 64, PER16 = 8;
@@ -57,6 +81,12 @@ template <> __device__ __forceinline__ u32x4 xform_piece<__bf16>(u32x4 v, float 
     for (int i = 0; i < 8; ++i) h[i] = (__bf16)Elem<__bf16>::silu((float)h[i] * s);
     return __builtin_bit_cast(u32x4, h);
 }
+template <> __device__ __forceinline__ u32x4 xform_piece<_Float16>(u32x4 v, float s) {
+    f16x8 h = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (_Float16)Elem<_Float16>::silu((float)h[i] * s);
+    return __builtin_bit_cast(u32x4, h);
+}
 
 __device__ __forceinline__ int src_pixel(int n, int y, int x, int Hs, int Ws, int resample) {
     if (resample == 1) { y *= 2; x *= 2; }
@@ -67,6 +97,11 @@ __device__ __forceinline__ int src_pixel(int n, int y, int x, int Hs, int Ws, in
 template <typename T> __device__ __forceinline__ f32x4 load4(const void* base, size_t idx);
 template <> __device__ __forceinline__ f32x4 load4<float>(const void* base, size_t idx) {
     return *(const f32x4*)((const float*)base + idx);
+}
+template <> __device__ __forceinline__ f32x4 load4<_Float16>(const void* base, size_t idx) {
+    f16x4 h = *(const f16x4*)((const _Float16*)base + idx);
+    f32x4 f = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    return f;
 }
 template <> __device__ __forceinline__ f32x4 load4<__bf16>(const void* base, size_t idx) {
     bf16x4 h = *(const bf16x4*)((const __bf16*)base + idx);
@@ -110,15 +145,16 @@ __device__ __forceinline__ float epilogue4(const ConvParams& p, int n, int y, in
                 *(f32x4*)((float*)p.out2 + (size_t)pix * p.out_cstride + co) = a;
             }
         } else {
-            bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-            *(bf16x4*)((__bf16*)p.out + (size_t)pix * p.out_cstride + co) = h;
+            typedef typename Half<T>::x4 hx4;
+            hx4 h = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+            *(hx4*)((T*)p.out + (size_t)pix * p.out_cstride + co) = h;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { float f = (float)h[k]; ss += f * f; }
             if (p.out2) {  // from the ROUNDED value: bit-identical to applying the activation while staging the consumer's patch
-                bf16x4 a;
+                hx4 a;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) a[k] = (__bf16)Elem<T>::silu((float)h[k] * p.out2_scale);
-                *(bf16x4*)((__bf16*)p.out2 + (size_t)pix * p.out_cstride + co) = a;
+                for (int k = 0; k < 4; ++k) a[k] = (T)Elem<T>::silu((float)h[k] * p.out2_scale);
+                *(hx4*)((T*)p.out2 + (size_t)pix * p.out_cstride + co) = a;
             }
         }
     }

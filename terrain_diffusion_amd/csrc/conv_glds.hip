@@ -24,9 +24,10 @@ namespace td {
 #define TD_TACC(acc, a, b)
 #endif
 
-template <int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N>
+template <typename T, int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4 < 2 ? 2 : (WAVES_M * WAVES_N + 3) / 4) void conv_glds_kernel(const ConvParams p) {
-    typedef __bf16 T;
+    typedef typename Half<T>::x8 hx8;
+    typedef typename Half<T>::x4 hx4;
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
     constexpr int TPIX = TH * TW, BM = NIMG * TPIX;
     constexpr int PH = TH + 2, PW = TW == 8 ? 12 : TW + 2, PPI = PH * PW, NPATCH = NIMG * PPI;  // 8-wide: 2 pad columns (see frag_pixel)
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
     {                                                                                                        \
         _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                                    \
             _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                \
-                acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WF[j_]), __builtin_bit_cast(bf16x8, XF[i_]), acc[i_][j_], 0, 0, 0); \
+                acc[i_][j_] = Half<T>::mfma32(__builtin_bit_cast(hx8, WF[j_]), __builtin_bit_cast(hx8, XF[i_]), acc[i_][j_]); \
     }
     // The tap's barrier sits between k-steps 1 and 2 and does NOT drain the LDS queue; the next tap's first
     // two k-steps of fragments are requested behind this tap's last MFMAs, so no fragment read is ever waited for right after
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
                                 const u32x4 w = *(const u32x4*)(rrow + j * 32 + m * 16);
                                 unsigned w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
                                 swap_halves(w0, w2); swap_halves(w1, w3);
-                                const bf16x4 ra = __builtin_bit_cast(bf16x4, u32x2{w0, w1}), rb = __builtin_bit_cast(bf16x4, u32x2{w2, w3});
+                                const hx4 ra = __builtin_bit_cast(hx4, u32x2{w0, w1}), rb = __builtin_bit_cast(hx4, u32x2{w2, w3});
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) { va[e] += rs * (float)ra[e]; vb[e] += rs * (float)rb[e]; }
                             }
@@ -414,8 +415,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
                                 for (int e = 0; e < 4; ++e) { va[e] = fminf(fmaxf(va[e], -p.clip), p.clip); vb[e] = fminf(fmaxf(vb[e], -p.clip), p.clip); }
                             }
                         }
-                        const bf16x4 ha = {(__bf16)va[0], (__bf16)va[1], (__bf16)va[2], (__bf16)va[3]};
-                        const bf16x4 hb = {(__bf16)vb[0], (__bf16)vb[1], (__bf16)vb[2], (__bf16)vb[3]};
+                        const hx4 ha = {(T)va[0], (T)va[1], (T)va[2], (T)va[3]};
+                        const hx4 hb = {(T)vb[0], (T)vb[1], (T)vb[2], (T)vb[3]};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { const float fa = (float)ha[e], fb = (float)hb[e]; ssj[j] += fa * fa + fb * fb; }
                         const u32x2 pa = __builtin_bit_cast(u32x2, ha), pb = __builtin_bit_cast(u32x2, hb);
@@ -423,9 +424,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
                         swap_halves(a0, b0); swap_halves(a1, b1);
                         *(u32x4*)(orow + j * 32 + m * 16) = u32x4{a0, a1, b0, b1};
                         if (p.out2) {  // the consumer's mp_silu(scale * x), from the rounded value (== what its patch staging would compute)
-                            bf16x4 ga, gb;
+                            hx4 ga, gb;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { ga[e] = (__bf16)Elem<T>::silu((float)ha[e] * p.out2_scale); gb[e] = (__bf16)Elem<T>::silu((float)hb[e] * p.out2_scale); }
+                            for (int e = 0; e < 4; ++e) { ga[e] = (T)Elem<T>::silu((float)ha[e] * p.out2_scale); gb[e] = (T)Elem<T>::silu((float)hb[e] * p.out2_scale); }
                             const u32x2 qa = __builtin_bit_cast(u32x2, ga), qb = __builtin_bit_cast(u32x2, gb);
                             unsigned c0 = qa[0], c1 = qa[1], d0 = qb[0], d1 = qb[1];
                             swap_halves(c0, d0); swap_halves(c1, d1);
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
 #endif
 }
 
-template <int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N>
+template <typename T, int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N>
 static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
     constexpr int NPATCH = NIMG * (TH + 2) * (TW == 8 ? 12 : TW + 2);
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
@@ -483,7 +484,7 @@ static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
     bool seen1 = false;  // the kernel's compile-time ring slots need every 3x3 segment to start on a multiple of 3 K-steps
     for (int s = 0; s < p.nseg; ++s) { if (p.seg[s].taps == 9 && seen1) return hipErrorInvalidValue; if (p.seg[s].taps != 9) seen1 = true; }
     const int grid = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * p.ksplit;
-    auto kern = conv_glds_kernel<TH, TW, NIMG, BN, WAVES_M, WAVES_N>;
+    auto kern = conv_glds_kernel<T, TH, TW, NIMG, BN, WAVES_M, WAVES_N>;
     // per (instantiation, device): hipFuncSetAttribute applies to the CURRENT device's copy of the kernel only
     static bool attr_set[64] = {};
     int dev_ = 0; (void)hipGetDevice(&dev_);
@@ -496,7 +497,7 @@ static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && p.ksplit > 1) {
         const size_t W_ = (size_t)p.N * p.H * p.W * ((p.CoutPad + 255) / 256);
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel<__bf16>, dim3((unsigned)((W_ + 3) / 4)), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel<T>, dim3((unsigned)((W_ + 3) / 4)), dim3(256), 0, st, p);
         e = hipGetLastError();
     }
     return e;
@@ -507,15 +508,20 @@ static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
 //               ~91 KB LDS -> one workgroup per CU
 //   1 "small" : 4 waves, 128-pixel tile (8x16, narrow maps 8x8 x 2 images), bn 128 -> waves 2x2 (64 px x 64 co), bn 96 -> 4x1 (32 px x 96 co);
 //               ~71 KB LDS -> two independent workgroups per CU whose prologues / epilogues / barrier stalls overlap
-hipError_t launch_conv_glds(const ConvParams& p, bool narrow, int bn, int variant, hipStream_t st) {
-    if (!narrow && bn == 192 && variant == 2) return launch_glds_cfg<16, 16, 1, 192, 4, 3>(p, st);
+template <typename T>
+static hipError_t launch_conv_glds_t(const ConvParams& p, bool narrow, int bn, int variant, hipStream_t st) {
     if (variant == 1) {
-        if (!narrow) return bn == 128 ? launch_glds_cfg<8, 16, 1, 128, 2, 2>(p, st) : launch_glds_cfg<8, 16, 1, 96, 4, 1>(p, st);
-        return bn == 128 ? launch_glds_cfg<8, 8, 2, 128, 2, 2>(p, st) : launch_glds_cfg<8, 8, 2, 96, 4, 1>(p, st);
+        if (!narrow) return bn == 128 ? launch_glds_cfg<T, 8, 16, 1, 128, 2, 2>(p, st) : launch_glds_cfg<T, 8, 16, 1, 96, 4, 1>(p, st);
+        return bn == 128 ? launch_glds_cfg<T, 8, 8, 2, 128, 2, 2>(p, st) : launch_glds_cfg<T, 8, 8, 2, 96, 4, 1>(p, st);
     }
-    if (!narrow && bn == 192) return variant == 2 ? launch_glds_cfg<16, 16, 1, 192, 4, 3>(p, st) : launch_glds_cfg<16, 16, 1, 192, 4, 2>(p, st);
-    if (!narrow) return bn == 128 ? launch_glds_cfg<16, 16, 1, 128, 4, 2>(p, st) : launch_glds_cfg<16, 16, 1, 96, 8, 1>(p, st);
-    return bn == 128 ? launch_glds_cfg<8, 8, 4, 128, 4, 2>(p, st) : launch_glds_cfg<8, 8, 4, 96, 8, 1>(p, st);
+    if (!narrow) return bn == 128 ? launch_glds_cfg<T, 16, 16, 1, 128, 4, 2>(p, st) : launch_glds_cfg<T, 16, 16, 1, 96, 8, 1>(p, st);
+    return bn == 128 ? launch_glds_cfg<T, 8, 8, 4, 128, 4, 2>(p, st) : launch_glds_cfg<T, 8, 8, 4, 96, 8, 1>(p, st);
+}
+
+// dtype: 1 bf16, 2 fp16 (this flavour has no fp32 form)
+hipError_t launch_conv_glds(const ConvParams& p, int dtype, bool narrow, int bn, int variant, hipStream_t st) {
+    if (bn != 96 && bn != 128) return hipErrorInvalidValue;
+    return dtype == 2 ? launch_conv_glds_t<_Float16>(p, narrow, bn, variant, st) : launch_conv_glds_t<__bf16>(p, narrow, bn, variant, st);
 }
 
 }  // namespace td

@@ -50,7 +50,7 @@ __device__ __forceinline__ void mfma_tap(const unsigned char* __restrict__ sa, c
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NTL; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, xf[i]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = Half<T>::mfma16(__builtin_bit_cast(typename Half<T>::x8, wf[j]), __builtin_bit_cast(typename Half<T>::x8, xf[i]), acc[i][j]);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -386,8 +386,9 @@ static hipError_t launch_t(const ConvParams& p, bool narrow, int bn, int flavor,
         default: return launch_cfg<T, 8, 8, 2, 64>(p, st);
     }
 }
-hipError_t launch_conv(const ConvParams& p, bool is_bf16, bool narrow, int bn, int flavor, hipStream_t st) {
-    return is_bf16 ? launch_t<__bf16>(p, narrow, bn, flavor, st) : launch_t<float>(p, narrow, bn, flavor, st);
+// dtype: 0 fp32 (exact-fp32 MFMA), 1 bf16, 2 fp16
+hipError_t launch_conv(const ConvParams& p, int dtype, bool narrow, int bn, int flavor, hipStream_t st) {
+    return dtype == 1 ? launch_t<__bf16>(p, narrow, bn, flavor, st) : dtype == 2 ? launch_t<_Float16>(p, narrow, bn, flavor, st) : launch_t<float>(p, narrow, bn, flavor, st);
 }
 
 }  // namespace td

@@ -45,9 +45,10 @@ namespace td {
 // wave that must see its weight pieces land every tap cannot leave patch loads in flight for more than two taps, and the patch comes from HBM
 // (~2.5 us under load).  With the roles split, patch pieces have eight taps to land and nobody ever waits for HBM in the steady state.
 // DMAP = false: register staging with the fused transform (pixel-norm / mp_silu), by all waves.
-template <int BN, int WAVES_M, int WAVES_N, bool DMAP>
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool DMAP>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
-    typedef __bf16 T;
+    typedef typename Half<T>::x8 hx8;
+    typedef typename Half<T>::x4 hx4;
     constexpr int TH = 16, TW = 16, NTHR = 512;
     constexpr int TPIX = TH * TW, BM = TPIX;
     constexpr int PH = TH + 2, PW = TW + 2, NPATCH = PH * PW;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
         _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)                                                  \
             _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                                \
                 _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                            \
-                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ks_][j_]), __builtin_bit_cast(bf16x8, xf[ks_][i_]), acc[i_][j_], 0, 0, 0); \
+                    acc[i_][j_] = Half<T>::mfma32(__builtin_bit_cast(hx8, wf[ks_][j_]), __builtin_bit_cast(hx8, xf[ks_][i_]), acc[i_][j_]); \
         __builtin_amdgcn_s_setprio(0);                                                                       \
     }
 #define PP_BARRIER()                                                                                         \
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
                         const float rs = p.res_scale * rnv[i];
                         unsigned w0 = rw[s][0], w1 = rw[s][1], w2 = rw[s][2], w3 = rw[s][3];
                         swap_halves(w0, w2); swap_halves(w1, w3);
-                        const bf16x4 ra = __builtin_bit_cast(bf16x4, u32x2{w0, w1}), rb4 = __builtin_bit_cast(bf16x4, u32x2{w2, w3});
+                        const hx4 ra = __builtin_bit_cast(hx4, u32x2{w0, w1}), rb4 = __builtin_bit_cast(hx4, u32x2{w2, w3});
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { va[e] += rs * (float)ra[e]; vb[e] += rs * (float)rb4[e]; }
                     }
@@ -341,8 +342,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
                         for (int e = 0; e < 4; ++e) { va[e] = fminf(fmaxf(va[e], -p.clip), p.clip); vb[e] = fminf(fmaxf(vb[e], -p.clip), p.clip); }
                     }
                 }
-                const bf16x4 ha = {(__bf16)va[0], (__bf16)va[1], (__bf16)va[2], (__bf16)va[3]};
-                const bf16x4 hb = {(__bf16)vb[0], (__bf16)vb[1], (__bf16)vb[2], (__bf16)vb[3]};
+                const hx4 ha = {(T)va[0], (T)va[1], (T)va[2], (T)va[3]};
+                const hx4 hb = {(T)vb[0], (T)vb[1], (T)vb[2], (T)vb[3]};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float fa = (float)ha[e], fb = (float)hb[e]; ssv[i][j] += fa * fa + fb * fb; }
                 const u32x2 pa = __builtin_bit_cast(u32x2, ha), pb2 = __builtin_bit_cast(u32x2, hb);
@@ -351,9 +352,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
                 const size_t oo = (size_t)pixv[i] * p.out_cstride + co0 + wn * WN + 8 * lh + j * 32 + m * 16;
                 if (okv[i]) *(u32x4*)((T*)p.out + oo) = u32x4{a0, a1, b0, b1};
                 if (p.out2) {  // the consumer's mp_silu(scale * x), from the rounded value (== what its patch staging would compute)
-                    bf16x4 ga, gb;
+                    hx4 ga, gb;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { ga[e] = (__bf16)Elem<T>::silu((float)ha[e] * p.out2_scale); gb[e] = (__bf16)Elem<T>::silu((float)hb[e] * p.out2_scale); }
+                    for (int e = 0; e < 4; ++e) { ga[e] = (T)Elem<T>::silu((float)ha[e] * p.out2_scale); gb[e] = (T)Elem<T>::silu((float)hb[e] * p.out2_scale); }
                     const u32x2 qa = __builtin_bit_cast(u32x2, ga), qb = __builtin_bit_cast(u32x2, gb);
                     unsigned c0 = qa[0], c1 = qa[1], d0 = qb[0], d1 = qb[1];
                     swap_halves(c0, d0); swap_halves(c1, d1);
@@ -478,12 +479,12 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
 #undef PP_FETCH
 }
 
-template <int BN, int WAVES_M, int WAVES_N, bool DMAP>
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool DMAP>
 static hipError_t launch_pp_cfg(const ConvParams& p, int n_cus, hipStream_t st) {
     constexpr int NPATCH = 18 * 18, NTHR = 512;
     constexpr int NBI = (BN * 128 + NTHR * 16 - 1) / (NTHR * 16);
     const size_t lds = 3 * (size_t)NBI * NTHR * 16 + 2 * (size_t)((NPATCH * 9 + 63) / 64) * 1024 + 2 * NPATCH * 4;
-    auto kern = conv_pp_kernel<BN, WAVES_M, WAVES_N, DMAP>;
+    auto kern = conv_pp_kernel<T, BN, WAVES_M, WAVES_N, DMAP>;
     static bool attr_set[64] = {};
     int dev_ = 0; (void)hipGetDevice(&dev_);
     if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_]) {
@@ -501,7 +502,13 @@ static hipError_t launch_pp_cfg(const ConvParams& p, int n_cus, hipStream_t st) 
 }
 
 // bn 128 -> waves 4x2 (64 px x 64 co per wave), bn 96 -> 8x1 (32 px x 96 co).  Preconditions are the caller's (see conv_pp_eligible).
-hipError_t launch_conv_pp(const ConvParams& p, int bn, int n_cus, hipStream_t st) {
+template <typename T>
+static hipError_t launch_conv_pp_t(const ConvParams& p, int bn, int n_cus, bool dmap, hipStream_t st) {
+    if (dmap) return bn == 128 ? launch_pp_cfg<T, 128, 4, 2, true>(p, n_cus, st) : launch_pp_cfg<T, 96, 8, 1, true>(p, n_cus, st);
+    return bn == 128 ? launch_pp_cfg<T, 128, 4, 2, false>(p, n_cus, st) : launch_pp_cfg<T, 96, 8, 1, false>(p, n_cus, st);
+}
+
+hipError_t launch_conv_pp(const ConvParams& p, int dtype, int bn, int n_cus, hipStream_t st) {
     for (int s = 0; s < p.nseg; ++s) if (p.seg[s].taps != 9) return hipErrorInvalidValue;
     if (p.ksplit != 1 || p.out_f32 || (p.Cout & 7) || p.W < 16 || p.img_groups != p.N) return hipErrorInvalidValue;
     bool dmap = p.zeros != nullptr;  // LDS-DMA patch staging needs untransformed sources (and the zero page for the halo outside the image)
@@ -509,8 +516,7 @@ hipError_t launch_conv_pp(const ConvParams& p, int bn, int n_cus, hipStream_t st
 #ifdef TD_PP_NO_DMAP
     dmap = false;
 #endif
-    if (dmap) return bn == 128 ? launch_pp_cfg<128, 4, 2, true>(p, n_cus, st) : launch_pp_cfg<96, 8, 1, true>(p, n_cus, st);
-    return bn == 128 ? launch_pp_cfg<128, 4, 2, false>(p, n_cus, st) : launch_pp_cfg<96, 8, 1, false>(p, n_cus, st);
+    return dtype == 2 ? launch_conv_pp_t<_Float16>(p, bn, n_cus, dmap, st) : launch_conv_pp_t<__bf16>(p, bn, n_cus, dmap, st);
 }
 
 }  // namespace td

@@ -23,6 +23,14 @@
 
 using namespace td;
 
+// element-type dispatch for the kernels that exist in fp32 / bf16 / fp16 form (T_ is the storage type of the model `U`)
+#define TD_DISPATCH_T(U, ...)                                                       \
+    do {                                                                             \
+        if ((U)->dt == TD_DTYPE_BF16) { typedef __bf16 T_; __VA_ARGS__; }            \
+        else if ((U)->dt == TD_DTYPE_F16) { typedef _Float16 T_; __VA_ARGS__; }      \
+        else { typedef float T_; __VA_ARGS__; }                                      \
+    } while (0)
+
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIP_TRY(expr)                                                                                      \
@@ -32,6 +40,12 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     } while (0)
 
 // ------------------------------------------------------------------------------------------------ helpers
+static inline uint16_t f2h(float f) {  // IEEE binary16, round-to-nearest-even (the host compiler's _Float16 conversion)
+    _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
 static inline uint16_t f2bf(float f) {  // round-to-nearest-even, NaN-preserving
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -204,7 +218,8 @@ struct Plan {
 struct td_unet {
     td_engine* eng = nullptr;
     td_unet_config cfg;
-    bool bf16 = false;
+    bool bf16 = false;         // 16-bit storage (bf16 OR fp16): 64-channel K chunks, LDS-DMA / ping-pong conv flavours available
+    int dt = TD_DTYPE_F32;     // TD_DTYPE_*
     int chunk = 32;            // channels per 128-byte K chunk
     int emb_ch = 0, noise_dims = 0, c_total = 0;
     std::vector<Block> enc, dec;
@@ -355,7 +370,7 @@ static int pack_conv(td_unet* u, ConvWeights& cw) {
                             int ci = ch * chunk + q * per16 + e;
                             float v = 0.f;
                             if (ci < s.c_real) v = (*s.w)[(((size_t)co * s.cin_tot + s.cin_off + ci) * k * k) + tap] * s.mul;
-                            if (u->bf16) stage16[dst + e] = f2bf(v); else stage[dst + e] = v;
+                            if (u->bf16) stage16[dst + e] = u->dt == TD_DTYPE_F16 ? f2h(v) : f2bf(v); else stage[dst + e] = v;
                         }
                     }
     }
@@ -846,8 +861,7 @@ static int run_unet(td_unet* u, Plan& pl, int step) {
     for (auto& op : pl.ops) {
         if (op.kind == Op::ATTN) {
             mark();
-            if (u->bf16) hipLaunchKernelGGL(attn_kernel<__bf16>, dim3(pl.N, op.C / 64), dim3(256), 0, st, (const __bf16*)op.qkv, (__bf16*)op.att, op.tokens, op.C);
-            else hipLaunchKernelGGL(attn_kernel<float>, dim3(pl.N, op.C / 64), dim3(256), 0, st, (const float*)op.qkv, (float*)op.att, op.tokens, op.C);
+            TD_DISPATCH_T(u, hipLaunchKernelGGL(attn_kernel<T_>, dim3(pl.N, op.C / 64), dim3(256), 0, st, (const T_*)op.qkv, (T_*)op.att, op.tokens, op.C));
             mark(); if (prof) { ev_kind.push_back(1); ev_label.push_back(op.label); ev_flop.push_back(0.0); }
             HIP_TRY(hipGetLastError());
             continue;
@@ -855,8 +869,8 @@ static int run_unet(td_unet* u, Plan& pl, int step) {
         ConvParams p = op.p;
         if (op.cvec_off >= 0) p.cvec = cbase + op.cvec_off;
         mark();
-        hipError_t e = op.flavor == 3 ? launch_conv_pp(p, op.bn, u->eng->n_cus, st)
-                       : op.flavor == 2 ? launch_conv_glds(p, op.narrow, op.bn, op.glds_variant, st) : launch_conv(p, u->bf16, op.narrow, op.bn, 0, st);
+        hipError_t e = op.flavor == 3 ? launch_conv_pp(p, u->dt, op.bn, u->eng->n_cus, st)
+                       : op.flavor == 2 ? launch_conv_glds(p, u->dt, op.narrow, op.bn, op.glds_variant, st) : launch_conv(p, u->dt, op.narrow, op.bn, 0, st);
         mark(); if (prof) { ev_kind.push_back(0); char tag[96]; snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 3 ? "p" : op.flavor == 2 ? (op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit); ev_label.push_back(op.label + tag);
             double kk = 0; for (int s_ = 0; s_ < p.nseg; ++s_) kk += (double)p.seg[s_].C * p.seg[s_].taps;
             ev_flop.push_back(op.flavor >= 2 ? 2.0 * p.N * p.H * p.W * (double)p.Cout * kk : 0.0); }
@@ -935,9 +949,9 @@ int td_engine_profile_dump(td_engine* e, char* buf, int64_t capacity) {
 
 int td_unet_create(td_engine* e, const td_unet_config* cfg, int dtype, td_unet** out) {
     if (!e || !cfg || !out) return fail(TD_ERR_ARG, "null argument");
-    if (dtype != TD_DTYPE_F32 && dtype != TD_DTYPE_BF16) return fail(TD_ERR_ARG, "dtype");
+    if (dtype != TD_DTYPE_F32 && dtype != TD_DTYPE_BF16 && dtype != TD_DTYPE_F16) return fail(TD_ERR_ARG, "dtype");
     std::unique_ptr<td_unet> u(new td_unet());
-    u->eng = e; u->cfg = *cfg; u->bf16 = dtype == TD_DTYPE_BF16; u->chunk = u->bf16 ? 64 : 32;
+    u->eng = e; u->cfg = *cfg; u->dt = dtype; u->bf16 = dtype != TD_DTYPE_F32; u->chunk = u->bf16 ? 64 : 32;
     int rc = build_blocks(u.get());
     if (rc) return rc;
     *out = u.release();
@@ -1011,8 +1025,7 @@ int td_unet_forward(td_unet* u, int n, int H, int W, const float* x, const float
                                    hipMemcpyDeviceToDevice, st));
         }
     }
-    if (u->bf16) hipLaunchKernelGGL(prep_input_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)dx, (__bf16*)pl->xin, n, C, HW, u->chunk, 1.f, C);
-    else hipLaunchKernelGGL(prep_input_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)dx, (float*)pl->xin, n, C, HW, u->chunk, 1.f, C);
+    TD_DISPATCH_T(u, hipLaunchKernelGGL(prep_input_kernel<T_>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)dx, (T_*)pl->xin, n, C, HW, u->chunk, 1.f, C));
     if ((rc = run_unet(u, *pl, 0))) return rc;
     hipLaunchKernelGGL(unpack_output_kernel, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->F, (float*)os.dev, n, Co, HW, 8, 1.f);
     HIP_TRY(hipGetLastError());
@@ -1064,6 +1077,7 @@ int td_unet_read_activation(td_unet* u, int n, int H, int W, const char* label, 
                     size_t src = ((size_t)i * h * w + p) * cs + c;
                     float v;
                     if (f32out) v = ((const float*)raw.data())[src];
+                    else if (u->dt == TD_DTYPE_F16) { _Float16 h; memcpy(&h, (const uint16_t*)raw.data() + src, 2); v = (float)h; }
                     else { uint32_t b = (uint32_t)((const uint16_t*)raw.data())[src] << 16; memcpy(&v, &b, 4); }
                     out_host[((size_t)i * C + c) * h * w + p] = v;
                 }
@@ -1110,8 +1124,7 @@ static int stage_cond_img(td_unet* u, Plan& pl, int n, int HW, const float* cond
     int rc = to_device(u->eng, cond_img, (size_t)n * cimg * HW * 4, hold, &dimg);
     if (rc) return rc;
     hipStream_t st = u->eng->stream;
-    if (u->bf16) hipLaunchKernelGGL(write_cond_img_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)dimg, (__bf16*)pl.xin, n, cimg, HW, u->chunk, Cs);
-    else hipLaunchKernelGGL(write_cond_img_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)dimg, (float*)pl.xin, n, cimg, HW, u->chunk, Cs);
+    TD_DISPATCH_T(u, hipLaunchKernelGGL(write_cond_img_kernel<T_>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)dimg, (T_*)pl.xin, n, cimg, HW, u->chunk, Cs));
     HIP_TRY(hipGetLastError());
     return TD_OK;
 }
@@ -1159,19 +1172,16 @@ static int sample_edm_impl(td_unet* u, td_unet* guide, float gscale, int n, int 
     const float c_in0 = 1.f / sqrtf(sigmas_host[0] * sigmas_host[0] + sigma_data * sigma_data);
 
     auto enqueue = [&]() -> int {
-        if (u->bf16) hipLaunchKernelGGL(prep_input_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (__bf16*)pl->xin, n, C, HW, u->chunk, c_in0, Cin);
-        else hipLaunchKernelGGL(prep_input_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (float*)pl->xin, n, C, HW, u->chunk, c_in0, Cin);
+        TD_DISPATCH_T(u, hipLaunchKernelGGL(prep_input_kernel<T_>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (T_*)pl->xin, n, C, HW, u->chunk, c_in0, Cin));
         if (gpl) {
-            if (u->bf16) hipLaunchKernelGGL(prep_input_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (__bf16*)gpl->xin, n, C, HW, u->chunk, c_in0, Cin);
-            else hipLaunchKernelGGL(prep_input_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (float*)gpl->xin, n, C, HW, u->chunk, c_in0, Cin);
+            TD_DISPATCH_T(u, hipLaunchKernelGGL(prep_input_kernel<T_>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (T_*)gpl->xin, n, C, HW, u->chunk, c_in0, Cin));
         }
         const float* Fg = gpl ? (const float*)gpl->F : nullptr;
         for (int i = 0; i < n_steps; ++i) {
             int r = run_unet(u, *pl, i);
             if (r) return r;
             if (gpl && (r = run_unet(guide, *gpl, i))) return r;
-            if (u->bf16) hipLaunchKernelGGL(dpm_step_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (float*)pl->x->p, (float*)pl->m1->p, (const float*)pl->F, (__bf16*)pl->xin, n, C, HW, 8, u->chunk, ks[i], Fg, gscale, gpl ? (__bf16*)gpl->xin : (__bf16*)nullptr);
-            else hipLaunchKernelGGL(dpm_step_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (float*)pl->x->p, (float*)pl->m1->p, (const float*)pl->F, (float*)pl->xin, n, C, HW, 8, u->chunk, ks[i], Fg, gscale, gpl ? (float*)gpl->xin : (float*)nullptr);
+            TD_DISPATCH_T(u, hipLaunchKernelGGL(dpm_step_kernel<T_>, grid1((size_t)n * HW), dim3(256), 0, st, (float*)pl->x->p, (float*)pl->m1->p, (const float*)pl->F, (T_*)pl->xin, n, C, HW, 8, u->chunk, ks[i], Fg, gscale, gpl ? (T_*)gpl->xin : (T_*)nullptr));
         }
         HIP_TRY(hipGetLastError());
         return TD_OK;
@@ -1241,8 +1251,7 @@ int td_sample_consistency_img(td_unet* u, int n, int H, int W, float t, float si
     OutStage os;
     if ((rc = out_device(e, out, xbytes, hold, &os))) return rc;
     const float ct = cosf(t), sn = sinf(t);
-    if (u->bf16) hipLaunchKernelGGL(consistency_pre_kernel<__bf16>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (const float*)dz, (float*)pl->xt->p, (__bf16*)pl->xin, n, C, HW, u->chunk, ct, sn, sigma_data, Cin);
-    else hipLaunchKernelGGL(consistency_pre_kernel<float>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (const float*)dz, (float*)pl->xt->p, (float*)pl->xin, n, C, HW, u->chunk, ct, sn, sigma_data, Cin);
+    TD_DISPATCH_T(u, hipLaunchKernelGGL(consistency_pre_kernel<T_>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (const float*)dz, (float*)pl->xt->p, (T_*)pl->xin, n, C, HW, u->chunk, ct, sn, sigma_data, Cin));
     if ((rc = run_unet(u, *pl, 0))) return rc;
     hipLaunchKernelGGL(consistency_post_kernel, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->xt->p, (const float*)pl->F, (float*)os.dev, n, C, HW, 8, ct, sn, sigma_data);
     HIP_TRY(hipGetLastError());

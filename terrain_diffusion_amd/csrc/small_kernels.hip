@@ -401,13 +401,18 @@ __global__ void window_extract_kernel(const float* __restrict__ img, float* __re
 // explicit instantiations used by the engine
 template __global__ void attn_kernel<float>(const float*, float*, int, int);
 template __global__ void attn_kernel<__bf16>(const __bf16*, __bf16*, int, int);
+template __global__ void attn_kernel<_Float16>(const _Float16*, _Float16*, int, int);
 template __global__ void prep_input_kernel<float>(const float*, float*, int, int, int, int, float, int);
 template __global__ void prep_input_kernel<__bf16>(const float*, __bf16*, int, int, int, int, float, int);
+template __global__ void prep_input_kernel<_Float16>(const float*, _Float16*, int, int, int, int, float, int);
 template __global__ void write_cond_img_kernel<float>(const float*, float*, int, int, int, int, int);
 template __global__ void write_cond_img_kernel<__bf16>(const float*, __bf16*, int, int, int, int, int);
+template __global__ void write_cond_img_kernel<_Float16>(const float*, _Float16*, int, int, int, int, int);
 template __global__ void dpm_step_kernel<float>(float*, float*, const float*, float*, int, int, int, int, int, SchedCoef, const float*, float, float*);
 template __global__ void dpm_step_kernel<__bf16>(float*, float*, const float*, __bf16*, int, int, int, int, int, SchedCoef, const float*, float, __bf16*);
+template __global__ void dpm_step_kernel<_Float16>(float*, float*, const float*, _Float16*, int, int, int, int, int, SchedCoef, const float*, float, _Float16*);
 template __global__ void consistency_pre_kernel<float>(const float*, const float*, float*, float*, int, int, int, int, float, float, float, int);
 template __global__ void consistency_pre_kernel<__bf16>(const float*, const float*, float*, __bf16*, int, int, int, int, float, float, float, int);
+template __global__ void consistency_pre_kernel<_Float16>(const float*, const float*, float*, _Float16*, int, int, int, int, float, float, float, int);
 
 }  // namespace td

@@ -13,7 +13,7 @@ import torch
 from ._lib import UnetConfig, lib, check
 from .engine import get_engine, ptr, f32
 
-DTYPES = {"fp32": 0, "float32": 0, None: 0, torch.float32: 0, "bf16": 1, "bfloat16": 1, torch.bfloat16: 1}
+DTYPES = {"fp32": 0, "float32": 0, None: 0, torch.float32: 0, "bf16": 1, "bfloat16": 1, torch.bfloat16: 1, "fp16": 2, "float16": 2, torch.float16: 2}
 
 
 class EDMUnet2D:

@@ -177,6 +177,28 @@ def test_config2_grid8_end_to_end(td, base):
     assert rel_rms(y[0, :, :32, :32].cpu().numpy(), (ref[0][:, :32, :32] / 0.5).numpy()) < 2e-2
 
 
+def test_fp16_tile_variants_bit_identical_and_close_to_bf16(td):
+    """fp16 storage runs through the same conv flavours (v_mfma_f32_32x32x16_f16): the tile-shape identity holds there too, and the result sits
+    closer to the fp32 oracle than bf16's (10 vs 7 mantissa bits)."""
+    from oracle.unet import BASE_CONFIG, OracleUnet, synth_state_dict
+    from terrain_diffusion_amd.engine import get_engine
+    eng = get_engine("cuda")
+    sd = synth_state_dict(BASE_CONFIG, seed=1234)
+    m = td.EDMUnet2D(**BASE_CONFIG, dtype="fp16").load_state_dict(sd)
+    x, c = _batch_inputs(8, seed=9)
+    t = torch.full((8,), 0.7)
+    outs = {}
+    for k, o in {"big": dict(glds_splitk=0, glds_variant=0), "small": dict(glds_splitk=0, glds_variant=1), "pingpong": dict(glds_splitk=0, pp=2)}.items():
+        outs[k] = _forward_with(eng, m, x.cuda(), t, c.cuda(), 8, **o)[0]
+    assert torch.equal(outs["big"], outs["small"]) and torch.equal(outs["big"], outs["pingpong"])
+    with torch.no_grad():
+        ref = OracleUnet(BASE_CONFIG, sd)(x[:2], t[:2], [c[:2]])
+    err = rel_rms(outs["big"][:2].cpu().numpy(), ref.numpy())
+    print(f"fp16 base forward vs oracle: {err:.3e}")
+    assert err < 4e-3
+    m.close()
+
+
 def test_solver_order_one_is_honoured(td):
     """a scheduler with solver_order=1 must give first-order results on the engine path (it silently ran 2M before)."""
     from oracle import tiling

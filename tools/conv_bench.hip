@@ -44,11 +44,11 @@ int main(int argc, char** argv) {
         p.res = r; p.res_cstride = Cout; p.res_Hs = H; p.res_Ws = W; p.res_scale = 0.9f; p.clip = 256.f; p.out_sumsq = ssq; }
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) CK((flavor == 5 ? launch_conv_pp(p, bn, 256, st) : flavor >= 2 ? launch_conv_glds(p, narrow, bn, flavor - 2, st) : launch_conv(p, true, narrow, bn, flavor, st)));
+    for (int i = 0; i < 3; ++i) CK((flavor == 5 ? launch_conv_pp(p, 1, bn, 256, st) : flavor >= 2 ? launch_conv_glds(p, 1, narrow, bn, flavor - 2, st) : launch_conv(p, 1, narrow, bn, flavor, st)));
     CK(hipStreamSynchronize(st));
     const int reps = 20;
     CK(hipEventRecord(e0, st));
-    for (int i = 0; i < reps; ++i) CK((flavor == 5 ? launch_conv_pp(p, bn, 256, st) : flavor >= 2 ? launch_conv_glds(p, narrow, bn, flavor - 2, st) : launch_conv(p, true, narrow, bn, flavor, st)));
+    for (int i = 0; i < reps; ++i) CK((flavor == 5 ? launch_conv_pp(p, 1, bn, 256, st) : flavor >= 2 ? launch_conv_glds(p, 1, narrow, bn, flavor - 2, st) : launch_conv(p, 1, narrow, bn, flavor, st)));
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     double flop = 2.0 * M * Cout * Cin * taps;
@@ -57,13 +57,13 @@ int main(int argc, char** argv) {
     if (flavor == 5) {  // bit-exactness of the persistent ping-pong flavour against the LDS-DMA flavour (same K order, same MFMA)
         std::vector<uint16_t> o5(M * Cout), o2(M * Cout);
         CK(hipMemset(out, 0, M * Cout * 2));
-        CK(launch_conv_pp(p, bn, 256, st)); CK(hipStreamSynchronize(st));
+        CK(launch_conv_pp(p, 1, bn, 256, st)); CK(hipStreamSynchronize(st));
         CK(hipMemcpy(o5.data(), out, o5.size() * 2, hipMemcpyDeviceToHost));
         std::vector<float> s5, s2;
         if (p.out_sumsq) { s5.resize(M * (Cout / 32)); CK(hipMemcpy(s5.data(), p.out_sumsq, s5.size() * 4, hipMemcpyDeviceToHost)); }
         CK(hipMemset(out, 0, M * Cout * 2));
         ConvParams q = p; q.tiles_y = (H + 15) / 16;
-        CK(launch_conv_glds(q, narrow, bn, 0, st)); CK(hipStreamSynchronize(st));
+        CK(launch_conv_glds(q, 1, narrow, bn, 0, st)); CK(hipStreamSynchronize(st));
         CK(hipMemcpy(o2.data(), out, o2.size() * 2, hipMemcpyDeviceToHost));
         if (p.out_sumsq) { s2.resize(M * (Cout / 32)); CK(hipMemcpy(s2.data(), p.out_sumsq, s2.size() * 4, hipMemcpyDeviceToHost)); }
         size_t bad = 0, first = 0; for (size_t i = 0; i < o5.size(); ++i) if (o5[i] != o2[i]) { if (!bad) first = i; ++bad; }
