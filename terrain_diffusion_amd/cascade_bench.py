@@ -1,0 +1,91 @@
+"""`python bench.py --workload cascade`: BASELINE configs[4] shapes on ONE GPU -- the coarse -> latent (two blended trig-flow phases) -> decoder
+cascade through the lazy device-resident graph (WorldPipeline), then the output composition (elevation + climate), with the tile cache capped
+so that windows are evicted and recomputed while the region streams.
+
+A "step" = one fresh region of R x R decoded pixels requested in Q x Q-pixel `get()` calls (a server walking across the world); every step
+uses another region, so nothing is served from cache across steps.  value = decoded MP / s.  Stage models: the released 30m/90m
+architectures (coarse 128-ch single level, base 192-ch U-Net, decoder 64-ch U-Net at 512x512 / stride 384) with synthetic weights.
+Algorithmic work per decoded MP: decoder 9 330 GFLOP + latent 5 910 + coarse 3 = 15.24 TFLOP.
+"""
+import json
+import time
+
+import torch
+
+GFLOP_PER_MP = 15_243.0
+PEAK_BF16_TFLOPS = 2500.0
+COARSE_CONFIG = dict(image_size=16, in_channels=11, out_channels=6, model_channels=128, model_channel_mults=[1], layers_per_block=2, attn_resolutions=[],
+                     midblock_attention=False, concat_balance=0.5, conditional_inputs=[["float", 64, 0.2]] * 5, fourier_scale="pos")
+DECODER_CONFIG = dict(image_size=512, in_channels=5, out_channels=1, model_channels=64, model_channel_mults=[1, 2, 3, 4], layers_per_block=3, attn_resolutions=[],
+                      midblock_attention=False, concat_balance=0.5, conditional_inputs=[], fourier_scale="pos")
+
+
+def run_cascade(args, eng, dev, rank, world):
+    import terrain_diffusion_amd as td
+    from terrain_diffusion_amd.synthetic import synthetic_state_dict
+    from bench import BASE_CONFIG
+    dtype = "fp16" if args.dtype == "fp16" else args.dtype
+    models = []
+    for cfg, seed in ((COARSE_CONFIG, 11), (BASE_CONFIG, 1234), (DECODER_CONFIG, 2468)):
+        m = td.EDMUnet2D(**cfg, dtype=dtype, device=dev)
+        models.append(m.load_state_dict(synthetic_state_dict(m, seed=seed)))
+    R, Q = 3072, 1024                       # region and request size in decoded pixels (3 x 3 requests per step)
+    cache = 100 * 2 ** 20                   # the reference's default cache_limit (world_pipeline.py:311); one step produces ~150 MiB of windows -> streaming eviction
+    world_p = td.WorldPipeline.from_models(*models, seed=4242 + rank, dtype=dtype, device=dev, cache_limit=cache, latents_batch_size=64).bind()
+
+    def one_step(i):
+        i0, j0 = 100_000 * (i + 1), -50_000 * (i + 1)
+        out = None
+        for a in range(0, R, Q):
+            for b in range(0, R, Q):
+                out = world_p.get(i0 + a, j0 + b, i0 + a + Q, j0 + b + Q)
+        return out
+
+    def sync():
+        eng.synchronize()
+        torch.cuda.synchronize()
+    for i in range(args.warmup):
+        one_step(-(i + 1))
+    sync()
+    for t in (world_p.coarse, world_p.latents, world_p.residual):
+        t.windows_computed = 0
+    ev0 = world_p.tile_store.evictions
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(out["elev"]).all())
+    mp = R * R / 1e6
+    value = args.steps * mp / dt
+    # per-stage kernel time: one profiled (eager) request of fresh terrain
+    eng.set_option("profile", 1)
+    eng.profile_read(reset=True)
+    world_p.get(7_000_000, 7_000_000, 7_000_000 + Q, 7_000_000 + Q)
+    sync()
+    ops = eng.profile_ops()
+    conv_ms, conv_n, other_ms, other_n = eng.profile_read(reset=True)
+    eng.set_option("profile", 0)
+    by_level = {}
+    for label, ms, n in ops:
+        key = "coarse+latent 64x64 and below" if any(s in label for s in ("[64x64", "[32x32", "[16x16", "[8x8")) else "decoder levels " + label[label.find("[") + 1:].split(" ")[0] if "[" in label else "other"
+        by_level[key] = by_level.get(key, 0.0) + ms
+    tflops = value * GFLOP_PER_MP / 1e3
+    result = {
+        "metric": "terrain megapixels/sec (decoded) at fixed steps, 30m model", "value": round(value, 4), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4] shapes on one GPU: coarse -> 2-phase latent -> decoder (512x512 / stride 384) cascade through the lazy device-resident "
+                               f"graph + elevation/climate composition, {R}x{R} decoded pixels per step in {Q}x{Q} requests, window cache capped at {cache >> 20} MiB "
+                               "(streaming eviction)",
+                   "decoded_mp_per_step": mp, "windows_per_step": {k: round(t.windows_computed / args.steps, 1) for k, t in
+                                                                   (("coarse", world_p.coarse), ("latent_final_phase", world_p.latents), ("decoder", world_p.residual))},
+                   "cache_evictions_per_step": round((world_p.tile_store.evictions - ev0) / args.steps, 1)},
+        "roofline": {"bound": "mfma", "kernel": "td::conv_glds_kernel (all stages)", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "achieved": round(tflops, 2),
+                     "frac": round(tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                     "note": "end to end over the algorithmic 15.24 TFLOP per decoded MP (recomputed evicted windows are NOT counted as useful work)",
+                     "one_request_conv_kernel_ms": round(conv_ms, 2), "one_request_other_kernel_ms": round(other_ms, 2),
+                     "one_request_kernel_ms_by_resolution": {k: round(v, 2) for k, v in sorted(by_level.items())}},
+    }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
