@@ -164,6 +164,14 @@ int td_residual_plus(td_engine* e, const float* packed, const float* lowres_up, 
 int td_elev_finish(td_engine* e, const float* packed, const float* lowres_up, int Hp, int Wp, int oi, int oj, int h, int w, float res_mean,
                    float res_std, float* out);
 
+/* ---- attention (MFMA flash kernel, terrain_diffusion_amd/csrc/attn_mfma.hip) -------------------------------------------------
+ * out = softmax(scale * Q K^T) V per (batch, head); q: [B][H][Lq][D], k / v: [B][H][Lk][D], out: [B][H][Lq][D], fp32 at the boundary, bf16
+ * operands / fp32 accumulation inside; any Lq, Lk >= 1, 1 <= D <= 160.  normalize=1 first scales every q, k, v row to unit RMS,
+ * x / (1e-4 + ||x|| / sqrt(D)) -- UNetBlock.attn (terrain_diffusion/models/unet_block.py:102-108, with scale = 1 / sqrt(D)); normalize=0 with
+ * scale = 1 / sqrt(D) is the plain scaled-dot-product attention of the SD-v1.5 U-Net in annotated_infinite_panorama.py:109-134.  The engine's
+ * own U-Net uses the same kernel for its attention blocks in bf16 mode. */
+int td_attention(td_engine* e, const float* q, const float* k, const float* v, int B, int H, int Lq, int Lk, int D, float scale, int normalize, float* out);
+
 /* ---- synthetic conditioning map (terrain_diffusion/inference/synthetic_map.py:182-236, perlin_transform.py:41-45) ----
  * One channel of the coarse conditioning source over rows [i1, i1+rows) x cols [j1, j1+cols): gradient-noise FBm (x = row, y = col, scaled by
  * `frequency`; `octaves` octaves, lacunarity, gain; integer seed) pushed through the piecewise-linear quantile transfer src -> dst (n_quantiles

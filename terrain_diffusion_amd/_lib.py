@@ -55,6 +55,7 @@ _SIGS = {
     "td_blend_windows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int]),
     "td_blend_normalize": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "td_linear_weight_window": (C.c_int, [_P, C.c_int, _P]),
+    "td_attention": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P]),
     "td_perlin_map": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, _P, _P, C.c_int, _P]),
     "td_resample2d": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
     "td_residual_plus": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, _P]),

@@ -1,0 +1,234 @@
+// MFMA attention for gfx950: softmax(scale * Q K^T) V with generic query / key lengths and head dims 8..160, bf16 operands, fp32 accumulate.
+// Replaces the attention einsums of UNetBlock.attn (terrain_diffusion/models/unet_block.py:102-108: per-token unit-RMS q, k, v, logits / sqrt(C))
+// and covers the SD-v1.5 shapes of the panorama demo (annotated_infinite_panorama.py:109-134: self-attention 4096 x 4096 / 1024 x 1024 /
+// 256 x 256 with head dims 40 / 80 / 160, cross-attention against 77 text tokens).
+//
+// Two kernels:
+//   attn_pack_kernel  reads q, k, v through arbitrary element strides (the U-Net's interleaved NHWC qkv tensor, or plain [B][H][L][D]), applies
+//                     the optional per-token unit-RMS normalisation x / (1e-4 + ||x|| / sqrt(D)) (mp_layers.py:9-12, dim=2 of the
+//                     (N, heads, C, 3, HW) view), and writes bf16 operands in the shapes the MFMA kernel wants: Qp / Kp [B][H][L][Dp] (d padded to a
+//                     multiple of 16 with zeros) and V TRANSPOSED Vt [B][H][Dm][Lkp] (Dm = D rounded up to 32, keys padded to 64) with the 16 keys
+//                     of every group stored in the order {0-3, 8-11, 4-7, 12-15} -- see below.
+//   attn_mfma_kernel  flash-style forward.  One wave owns 32 queries; a 4-wave workgroup shares 64-key K / Vt tiles staged in LDS.
+//     * S^T = K Q^T on v_mfma_f32_32x32x16_bf16 with K as the A operand (rows = keys) and Q as the B operand (columns = queries): a lane then holds
+//       ONE query column (lane & 31) and 16 key rows per 32-key block, so the softmax row maximum / sum is a lane-local reduction plus one exchange
+//       with lane ^ 32 -- no LDS round trip, no 32-lane butterfly (guide T12).
+//     * O^T = V^T P^T with V^T as the A operand (rows = d) and P as the B operand: the B fragment of a 16-key step wants, per lane, 8 consecutive
+//       keys of its query -- which are exactly the 8 probabilities the lane already holds for that step, IF the contraction index (keys) is taken
+//       in the order the S^T accumulator delivers them (half-wave 0: keys 0-3, 8-11; half-wave 1: keys 4-7, 12-15 of each 16).  A contraction
+//       index may be permuted freely as long as both operands agree, so V^T is simply stored with that key order (attn_pack_kernel) and P never
+//       moves between lanes.
+//     * online softmax in fp32 with exp2 (scale * log2 e folded into the logits); keys beyond Lk are masked to -inf; O is rescaled per tile.
+// K / V^T rows in LDS are padded to an odd number of 16-byte slots, which makes every 16-lane ds_read_b128 group conflict-free.
+#include "conv_common.h"
+
+namespace td {
+
+struct AttnStrides { long b, h, t, c; };  // element strides of (batch, head, token, channel)
+
+// grid (ceil(L / 64), H, B) x 3 roles via blockIdx.x ranges is overkill: one launch per operand (which = 0 q, 1 k, 2 v)
+template <typename TIN>
+__global__ __launch_bounds__(256) void attn_pack_kernel(const TIN* __restrict__ src, AttnStrides st, int L, int D, int Dp, int Dm, int Lkp, int which, int normalize,
+                                                        __bf16* __restrict__ dst) {
+    // one wave per token: lanes stride over channels
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+    if (tok >= (which == 2 ? Lkp : L)) return;
+    const bool real = tok < L;
+    const TIN* row = src + b * st.b + h * st.h + (long)tok * st.t;
+    float v[3] = {0.f, 0.f, 0.f};  // D <= 192: up to 3 channels per lane
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int c = lane + 64 * j;
+        if (real && c < D) { v[j] = (float)row[(long)c * st.c]; ss += v[j] * v[j]; }
+    }
+    float inv = 1.f;
+    if (normalize) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+        inv = 1.f / (1e-4f + sqrtf(ss) / sqrtf((float)D));
+    }
+    if (which < 2) {
+        __bf16* out = dst + (((long)b * H + h) * L + tok) * Dp;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const int c = lane + 64 * j; if (c < Dp) out[c] = (__bf16)(v[j] * inv); }
+    } else {
+        const int pk = (tok & ~15) | (tok & 3) | (((tok >> 3) & 1) << 2) | (((tok >> 2) & 1) << 3);  // key order inside a group of 16 (see header)
+        __bf16* out = dst + ((long)b * H + h) * Dm * Lkp + pk;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const int c = lane + 64 * j; if (c < Dm) out[(long)c * Lkp] = (__bf16)(v[j] * inv); }
+    }
+}
+
+// DP16 = Dp / 16 (k-steps of Q K^T), DM32 = Dm / 32 (row blocks of O^T)
+template <int DP16, int DM32, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __restrict__ Qp, const __bf16* __restrict__ Kp, const __bf16* __restrict__ Vt, float* __restrict__ out_f32,
+                                                        __bf16* __restrict__ out_b16, AttnStrides ost, int Lq, int Lk, int Lkp, int D, float scale_log2e) {
+    constexpr int Dp = DP16 * 16, Dm = DM32 * 32, TK = 64;
+    constexpr int KSL = (Dp / 8) | 1, KPITCH = KSL * 16;      // K rows: odd number of 16-byte slots
+    constexpr int VPITCH = (TK / 8 + 1) * 16;                 // Vt rows: 64 keys = 8 slots -> 9
+    __shared__ __attribute__((aligned(16))) unsigned char s_k[TK * KPITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char s_v[Dm * VPITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+    constexpr int NTHR = 64 * NW;
+    const int q = blockIdx.x * (32 * NW) + wave * 32 + l31;
+    const bool qok = q < Lq;
+    // Q fragments (B operand): lane = query column, half-wave = which 8 of the 16 d of a k-step
+    u32x4 qf[DP16];
+    {
+        const __bf16* qrow = Qp + (((long)b * H + h) * Lq + (qok ? q : 0)) * Dp + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < DP16; ++ks) qf[ks] = qok ? *(const u32x4*)(qrow + ks * 16) : u32x4{0u, 0u, 0u, 0u};
+    }
+    f32x16 o[DM32];
+#pragma unroll
+    for (int d = 0; d < DM32; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -3.0e38f, l_run = 0.f;
+    const __bf16* kbase = Kp + ((long)b * H + h) * Lk * Dp;
+    const __bf16* vbase = Vt + ((long)b * H + h) * Dm * Lkp;
+    // tile staging is software-pipelined through registers: the global loads of tile t+1 are issued before tile t is computed and written to
+    // LDS after it, so an HBM / L2 round trip is never waited for on the critical path
+    constexpr int KPIECES = TK * (Dp / 8), VPIECES = Dm * (TK / 8);
+    constexpr int KIT = (KPIECES + NTHR - 1) / NTHR, VIT = (VPIECES + NTHR - 1) / NTHR;
+    u32x4 kreg[KIT], vreg[VIT];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) {
+            const int e = tid + it * NTHR, r = e / (Dp / 8), sl = e % (Dp / 8);
+            kreg[it] = (e < KPIECES && k0 + r < Lk) ? *(const u32x4*)(kbase + (long)(k0 + r) * Dp + sl * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            const int e = tid + it * NTHR, r = e / (TK / 8), sl = e % (TK / 8);
+            vreg[it] = e < VPIECES ? *(const u32x4*)(vbase + (long)r * Lkp + k0 + sl * 8) : u32x4{0u, 0u, 0u, 0u};   // Lkp is a multiple of 64, padding keys are zero
+        }
+    };
+    load_tile(0);
+    for (int k0 = 0; k0 < Lk; k0 += TK) {
+        __syncthreads();  // the previous tile's readers are done
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) {
+            const int e = tid + it * NTHR, r = e / (Dp / 8), sl = e % (Dp / 8);
+            if (e < KPIECES) *(u32x4*)(s_k + r * KPITCH + sl * 16) = kreg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            const int e = tid + it * NTHR, r = e / (TK / 8), sl = e % (TK / 8);
+            if (e < VPIECES) *(u32x4*)(s_v + r * VPITCH + sl * 16) = vreg[it];
+        }
+        __syncthreads();
+        if (k0 + TK < Lk) load_tile(k0 + TK);
+        // ---- S^T = K Q^T for two 32-key blocks
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < DP16; ++ks) {
+                const u32x4 kf = *(const u32x4*)(s_k + (kb * 32 + l31) * KPITCH + ks * 32 + lh * 16);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[ks]), s[kb], 0, 0, 0);
+            }
+        }
+        // ---- online softmax for this lane's query: keys of register r of block kb = k0 + 32 kb + 8 (r / 4) + 4 lh + r % 4
+        float mt = -3.0e38f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+                s[kb][r] = key < Lk ? s[kb][r] * scale_log2e : -3.0e38f;
+                mt = fmaxf(mt, s[kb][r]);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        // the running maximum rarely moves after the first tiles: rescaling O and the denominator is skipped (wave-uniformly) when no query of
+        // the wave saw a new maximum
+        const bool moved = __builtin_amdgcn_ballot_w64(m_new > m_run) != 0;
+        const float alpha = moved ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.f;
+        float psum = 0.f;
+        u32x4 pf[4];  // B fragments of the four 16-key steps: 8 probabilities each, already in contraction order
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                bf16x8 pb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float p = __builtin_amdgcn_exp2f(s[kb][jj * 8 + e] - m_new);   // v_exp_f32: inputs <= 0, flushing tiny results to 0 is fine
+                    pb[e] = (__bf16)p;
+                    psum += (float)pb[e];  // the denominator sums what the numerator uses (the rounded probabilities)
+                }
+                pf[kb * 2 + jj] = __builtin_bit_cast(u32x4, pb);
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        // ---- O^T = alpha O^T + V^T P^T
+#pragma unroll
+        for (int d = 0; d < DM32; ++d) {
+            if (moved) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            }
+#pragma unroll
+            for (int st4 = 0; st4 < 4; ++st4) {
+                const u32x4 vf = *(const u32x4*)(s_v + (d * 32 + l31) * VPITCH + st4 * 32 + lh * 16);
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf[st4]), o[d], 0, 0, 0);
+            }
+        }
+    }
+    const float linv = 1.f / (l_run + __shfl_xor(l_run, 32));
+    if (qok) {
+#pragma unroll
+        for (int d = 0; d < DM32; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = d * 32 + 8 * g + 4 * lh;  // four consecutive channels
+                const long off = b * ost.b + h * ost.h + (long)q * ost.t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c0 + e < D) {
+                        const float val = o[d][g * 4 + e] * linv;
+                        if (out_f32) out_f32[off + (long)(c0 + e) * ost.c] = val; else out_b16[off + (long)(c0 + e) * ost.c] = (__bf16)val;
+                    }
+            }
+    }
+}
+
+// ---- host launchers
+template <typename TIN>
+static hipError_t attn_pack(const TIN* q, const TIN* k, const TIN* v, AttnStrides sq, AttnStrides sk, AttnStrides sv, int B, int H, int Lq, int Lk, int D, int normalize,
+                            __bf16* Qp, __bf16* Kp, __bf16* Vt, hipStream_t st) {
+    const int Dp = (D + 15) / 16 * 16, Dm = (D + 31) / 32 * 32, Lkp = (Lk + 63) / 64 * 64;
+    hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lq + 3) / 4, H, B), dim3(256), 0, st, q, sq, Lq, D, Dp, Dm, Lkp, 0, normalize, Qp);
+    hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lk + 3) / 4, H, B), dim3(256), 0, st, k, sk, Lk, D, Dp, Dm, Lkp, 1, normalize, Kp);
+    hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lkp + 3) / 4, H, B), dim3(256), 0, st, v, sv, Lk, D, Dp, Dm, Lkp, 2, normalize, Vt);
+    return hipGetLastError();
+}
+
+static hipError_t attn_mfma(const __bf16* Qp, const __bf16* Kp, const __bf16* Vt, float* out_f32, __bf16* out_b16, AttnStrides ost, int B, int H, int Lq, int Lk, int D,
+                            float scale, hipStream_t st) {
+    const int Dp16 = (D + 15) / 16, Dm32 = (D + 31) / 32, Lkp = (Lk + 63) / 64 * 64;
+    const float sl2 = scale * 1.4426950408889634f;
+    // 8 waves (256 queries) per workgroup when there are enough queries to fill the chip that way: the K / V^T tile is staged once per workgroup
+    const bool big = (long)((Lq + 255) / 256) * H * B >= 256;
+    const dim3 grid(big ? (Lq + 255) / 256 : (Lq + 127) / 128, H, B), blk(big ? 512 : 256);
+#define TD_ATTN_CASE(A, M) if (Dp16 == A && Dm32 == M) {                                                                                        \
+        if (big) hipLaunchKernelGGL((attn_mfma_kernel<A, M, 8>), grid, blk, 0, st, Qp, Kp, Vt, out_f32, out_b16, ost, Lq, Lk, Lkp, D, sl2);      \
+        else hipLaunchKernelGGL((attn_mfma_kernel<A, M, 4>), grid, blk, 0, st, Qp, Kp, Vt, out_f32, out_b16, ost, Lq, Lk, Lkp, D, sl2);          \
+        return hipGetLastError(); }
+    TD_ATTN_CASE(1, 1) TD_ATTN_CASE(2, 1) TD_ATTN_CASE(3, 2) TD_ATTN_CASE(4, 2) TD_ATTN_CASE(5, 3) TD_ATTN_CASE(6, 3) TD_ATTN_CASE(7, 4) TD_ATTN_CASE(8, 4) TD_ATTN_CASE(9, 5) TD_ATTN_CASE(10, 5)
+#undef TD_ATTN_CASE
+    return hipErrorInvalidValue;
+}
+
+static size_t attn_workspace_elems(int B, int H, int Lq, int Lk, int D, size_t* qn, size_t* kn, size_t* vn) {
+    const size_t Dp = (D + 15) / 16 * 16, Dm = (D + 31) / 32 * 32, Lkp = (Lk + 63) / 64 * 64;
+    *qn = (size_t)B * H * Lq * Dp; *kn = (size_t)B * H * Lk * Dp; *vn = (size_t)B * H * Dm * Lkp;
+    return *qn + *kn + *vn;
+}
+
+}  // namespace td

@@ -20,6 +20,7 @@
 #include "conv_pp.hip"
 #include "small_kernels.hip"
 #include "compose_kernels.hip"
+#include "attn_mfma.hip"
 
 using namespace td;
 
@@ -188,6 +189,7 @@ struct Op {
     int out_C = 0, out_H = 0, out_W = 0;  // output tensor geometry (debug read-back)
     // ATTN
     const void* qkv = nullptr; void* att = nullptr; int tokens = 0, C = 0;
+    void* attn_ws = nullptr;   // bf16 mode: packed Qp | Kp | Vt operands of the MFMA attention kernel (attn_mfma.hip)
     std::string label;
 };
 
@@ -520,7 +522,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
     // every option the plan builder reads is part of the cache key (a plan built under other options must never be reused)
     static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn", "pp",
                                                "pp_min_items_per_cu", "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
-                                               "bn128_min_wgs"};
+                                               "bn128_min_wgs", "attn_mfma"};
     std::string key = std::to_string(N) + "_" + std::to_string(H) + "_" + std::to_string(W);
     for (const char* o : kPlanOptions) key += "_" + std::to_string((long long)u->eng->option(o, -7));
     auto it = u->plans.find(key);
@@ -681,6 +683,18 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
         return TD_OK;
     };
 
+    // bf16 mode: attention blocks run on the MFMA kernel (attn_mfma.hip); its packed operands live in a per-op workspace
+    auto attn_workspace = [&](Op& a) -> int {
+        if (u->dt != TD_DTYPE_BF16 || u->eng->option("attn_mfma", 1) == 0) return TD_OK;
+        size_t qn, kn, vn;
+        const size_t tot = attn_workspace_elems(N, a.C / 64, a.tokens, a.tokens, 64, &qn, &kn, &vn);
+        void* ws;
+        int r = new_buf(pl, tot * 2, &ws);
+        if (r) return r;
+        a.attn_ws = ws;
+        return TD_OK;
+    };
+
     // input tensor (ones channel appended, zero padded to one K chunk)
     Tensor xin;
     xin.C = chunk; xin.cstride = chunk; xin.H = H; xin.W = W;
@@ -709,11 +723,12 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
             if ((rc = conv(b.name + ".conv_res0", {{&xs, b.cout, 9, rs, 2, 1.f}}, h, w, EPI_EMB_SILU, b.cvec_off, nullptr, 0, false, 0.f, false, false, &y1))) return rc;
             if ((rc = conv(b.name + ".conv_res1", {{&y1, b.cout, 9, 0, 0, 1.f}}, h, w, EPI_RESIDUAL, -1, &xs, rs, true, b.attn ? 0.f : 256.f, next_norms && !b.attn, false, &o))) return rc;
             if (b.attn) {
-                if (h * w > 64) return fail(TD_ERR_UNSUPPORTED, "attention supports <= 64 tokens: " + b.name);
+                if (h * w > 64 && u->dt != TD_DTYPE_BF16) return fail(TD_ERR_UNSUPPORTED, "attention over more than 64 tokens needs bf16 mode (MFMA kernel): " + b.name);
                 Tensor qkv, att, o2;
                 if ((rc = conv(b.name + ".attn_qkv", {{&o, b.cout, 1, 0, 0, 1.f}}, h, w, EPI_PLAIN, -1, nullptr, 0, false, 0.f, false, false, &qkv))) return rc;
                 if ((rc = new_tensor(b.cout, h, w, false, 0, &att))) return rc;
                 Op a; a.kind = Op::ATTN; a.qkv = qkv.ptr; a.att = att.ptr; a.tokens = h * w; a.C = b.cout; a.label = b.name + ".attn";
+                if ((rc = attn_workspace(a))) return rc;
                 pl.ops.push_back(a);
                 if ((rc = conv(b.name + ".attn_proj", {{&att, b.cout, 1, 0, 0, 1.f}}, h, w, EPI_RESIDUAL, -1, &o, 0, false, 256.f, next_norms, false, &o2))) return rc;
                 o = o2;
@@ -744,11 +759,12 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
         } else res = &cur;
         if ((rc = conv(b.name + ".conv_res1", s1, h, w, EPI_RESIDUAL, -1, res, b.resample, false, b.attn ? 0.f : 256.f, false, false, &o))) return rc;
         if (b.attn) {
-            if (h * w > 64) return fail(TD_ERR_UNSUPPORTED, "attention supports <= 64 tokens: " + b.name);
+            if (h * w > 64 && u->dt != TD_DTYPE_BF16) return fail(TD_ERR_UNSUPPORTED, "attention over more than 64 tokens needs bf16 mode (MFMA kernel): " + b.name);
             Tensor qkv, att, o2;
             if ((rc = conv(b.name + ".attn_qkv", {{&o, b.cout, 1, 0, 0, 1.f}}, h, w, EPI_PLAIN, -1, nullptr, 0, false, 0.f, false, false, &qkv))) return rc;
             if ((rc = new_tensor(b.cout, h, w, false, 0, &att))) return rc;
             Op a; a.kind = Op::ATTN; a.qkv = qkv.ptr; a.att = att.ptr; a.tokens = h * w; a.C = b.cout; a.label = b.name + ".attn";
+            if ((rc = attn_workspace(a))) return rc;
             pl.ops.push_back(a);
             if ((rc = conv(b.name + ".attn_proj", {{&att, b.cout, 1, 0, 0, 1.f}}, h, w, EPI_RESIDUAL, -1, &o, 0, false, 256.f, false, false, &o2))) return rc;
             o = o2;
@@ -861,6 +877,17 @@ static int run_unet(td_unet* u, Plan& pl, int step) {
     for (auto& op : pl.ops) {
         if (op.kind == Op::ATTN) {
             mark();
+            if (op.attn_ws) {   // bf16: pack (de-interleave + unit-RMS norm) -> MFMA flash kernel; unet_block.py:102-108
+                const int Hh = op.C / 64, L = op.tokens;
+                size_t qn, kn, vn;
+                attn_workspace_elems(pl.N, Hh, L, L, 64, &qn, &kn, &vn);
+                __bf16 *Qp = (__bf16*)op.attn_ws, *Kp = Qp + qn, *Vt = Kp + kn;
+                const __bf16* qkv = (const __bf16*)op.qkv;
+                const AttnStrides si = {(long)L * 3 * op.C, 64L * 3, 3L * op.C, 3L}, so = {(long)L * op.C, 64L, (long)op.C, 1L};
+                hipError_t ea = attn_pack<__bf16>(qkv, qkv + 1, qkv + 2, si, si, si, pl.N, Hh, L, L, 64, 1, Qp, Kp, Vt, st);
+                if (ea == hipSuccess) ea = attn_mfma(Qp, Kp, Vt, nullptr, (__bf16*)op.att, so, pl.N, Hh, L, L, 64, 0.125f, st);
+                if (ea != hipSuccess) return fail(TD_ERR_HIP, std::string("attention launch: ") + hipGetErrorString(ea));
+            } else
             TD_DISPATCH_T(u, hipLaunchKernelGGL(attn_kernel<T_>, dim3(pl.N, op.C / 64), dim3(256), 0, st, (const T_*)op.qkv, (T_*)op.att, op.tokens, op.C));
             mark(); if (prof) { ev_kind.push_back(1); ev_label.push_back(op.label); ev_flop.push_back(0.0); }
             HIP_TRY(hipGetLastError());
@@ -1493,6 +1520,31 @@ int td_perlin_map(td_engine* e, int rows, int cols, int i1, int j1, int seed, fl
     HIP_TRY(hipGetLastError());
     if ((rc = out_finish(e, os))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
+    return TD_OK;
+}
+
+// ---- generic attention (row N1): softmax(scale * Q K^T) V on the MFMA kernel
+int td_attention(td_engine* e, const float* q, const float* k, const float* v, int B, int H, int Lq, int Lk, int D, float scale, int normalize, float* out) {
+    DevGuard dg_(e->device);
+    if (B < 1 || H < 1 || Lq < 1 || Lk < 1 || D < 1 || D > 160) return fail(TD_ERR_ARG, "td_attention: 1 <= D <= 160, positive sizes");
+    hipStream_t st = e->stream;
+    std::vector<Buf> hold;
+    const void *dq, *dk, *dv;
+    int rc;
+    if ((rc = to_device(e, q, (size_t)B * H * Lq * D * 4, hold, &dq)) || (rc = to_device(e, k, (size_t)B * H * Lk * D * 4, hold, &dk)) ||
+        (rc = to_device(e, v, (size_t)B * H * Lk * D * 4, hold, &dv))) return rc;
+    OutStage os;
+    if ((rc = out_device(e, out, (size_t)B * H * Lq * D * 4, hold, &os))) return rc;
+    size_t qn, kn, vn;
+    const size_t tot = attn_workspace_elems(B, H, Lq, Lk, D, &qn, &kn, &vn);
+    Buf ws(new DevBuf());
+    HIP_TRY(ws->alloc(tot * 2, false));
+    __bf16 *Qp = (__bf16*)ws->p, *Kp = Qp + qn, *Vt = Kp + kn;
+    const AttnStrides sq = {(long)H * Lq * D, (long)Lq * D, (long)D, 1L}, sk = {(long)H * Lk * D, (long)Lk * D, (long)D, 1L};
+    HIP_TRY(attn_pack<float>((const float*)dq, (const float*)dk, (const float*)dv, sq, sk, sk, B, H, Lq, Lk, D, normalize, Qp, Kp, Vt, st));
+    HIP_TRY(attn_mfma(Qp, Kp, Vt, (float*)os.dev, nullptr, sq, B, H, Lq, Lk, D, scale, st));
+    if ((rc = out_finish(e, os))) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
     return TD_OK;
 }
 
