@@ -53,18 +53,31 @@ template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int CHUNK = 32, PER16 = 4;
     static __device__ __forceinline__ float silu(float x) { return x / (1.f + expf(-x)) * (1.f / 0.596f); }
+    static __device__ __forceinline__ float silu_scaled(float x, float s) { return silu(x * s); }   // mp_silu(s x), exact-fp32 mode
 };
+// 16-bit modes: mp_silu(s x) = (s x) / (1 + exp(-s x)) / 0.596 is evaluated as (x * k2) * rcp(1 + exp2(x * k1)), k1 = -s log2(e), k2 = s / 0.596
+// (v_exp_f32 / v_rcp_f32, the scale folded into the two constants).  It is the SAME expression wherever the activation is applied -- patch
+// staging of the consumer, second output of the producer, emb-scale epilogue -- so the choice of the place never changes a bit.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct SiluK { float k1, k2; };
+__device__ __forceinline__ SiluK silu_k(float s) { return SiluK{s * -1.4426950408889634f, s * (1.f / 0.596f)}; }
+__device__ __forceinline__ float silu_k1(float x, SiluK k) { return (x * k.k2) * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * k.k1)); }
+__device__ __forceinline__ f32x2 silu_k2(f32x2 x, SiluK k) {  // two elements: the multiplies and the add are v_pk_*_f32
+    const f32x2 t = x * k.k1;
+    f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    e = e + 1.f;
+    const f32x2 r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+    return (x * k.k2) * r;
+}
 template <> struct Elem<_Float16> {
     static constexpr int CHUNK = 64, PER16 = 8;
-    static __device__ __forceinline__ float silu(float x) {
-        return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)) * (1.f / 0.596f);
-    }
+    static __device__ __forceinline__ float silu(float x) { return silu_k1(x, silu_k(1.f)); }
+    static __device__ __forceinline__ float silu_scaled(float x, float s) { return silu_k1(x, silu_k(s)); }
 };
 template <> struct Elem<__bf16> {
     static constexpr int CHUNK = 64, PER16 = 8;
-    static __device__ __forceinline__ float silu(float x) {
-        return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)) * (1.f / 0.596f);
-    }
+    static __device__ __forceinline__ float silu(float x) { return silu_k1(x, silu_k(1.f)); }
+    static __device__ __forceinline__ float silu_scaled(float x, float s) { return silu_k1(x, silu_k(s)); }
 };
 
 // mp_silu(s*x) on one 16-byte piece
@@ -77,14 +90,22 @@ template <> __device__ __forceinline__ u32x4 xform_piece<float>(u32x4 v, float s
 }
 template <> __device__ __forceinline__ u32x4 xform_piece<__bf16>(u32x4 v, float s) {
     bf16x8 h = __builtin_bit_cast(bf16x8, v);
+    const SiluK k = silu_k(s);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) h[i] = (__bf16)Elem<__bf16>::silu((float)h[i] * s);
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2 a = silu_k2(f32x2{(float)h[i], (float)h[i + 1]}, k);
+        h[i] = (__bf16)a.x; h[i + 1] = (__bf16)a.y;
+    }
     return __builtin_bit_cast(u32x4, h);
 }
 template <> __device__ __forceinline__ u32x4 xform_piece<_Float16>(u32x4 v, float s) {
     f16x8 h = __builtin_bit_cast(f16x8, v);
+    const SiluK k = silu_k(s);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) h[i] = (_Float16)Elem<_Float16>::silu((float)h[i] * s);
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2 a = silu_k2(f32x2{(float)h[i], (float)h[i + 1]}, k);
+        h[i] = (_Float16)a.x; h[i + 1] = (_Float16)a.y;
+    }
     return __builtin_bit_cast(u32x4, h);
 }
 
@@ -141,7 +162,7 @@ __device__ __forceinline__ float epilogue4(const ConvParams& p, int n, int y, in
             if (p.out2) {
                 f32x4 a;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) a[k] = Elem<T>::silu(v[k] * p.out2_scale);
+                for (int k = 0; k < 4; ++k) a[k] = Elem<T>::silu_scaled(v[k], p.out2_scale);
                 *(f32x4*)((float*)p.out2 + (size_t)pix * p.out_cstride + co) = a;
             }
         } else {
@@ -153,7 +174,7 @@ __device__ __forceinline__ float epilogue4(const ConvParams& p, int n, int y, in
             if (p.out2) {  // from the ROUNDED value: bit-identical to applying the activation while staging the consumer's patch
                 hx4 a;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) a[k] = (T)Elem<T>::silu((float)h[k] * p.out2_scale);
+                for (int k = 0; k < 4; ++k) a[k] = (T)Elem<T>::silu_scaled((float)h[k], p.out2_scale);
                 *(hx4*)((T*)p.out2 + (size_t)pix * p.out_cstride + co) = a;
             }
         }
@@ -180,6 +201,63 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void swap_halves(unsigned& a, unsigned& b) {
     auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
     a = r[0]; b = r[1];
+}
+
+// One unit of the wide 16-bit epilogue (conv_glds.hip, conv_pp.hip): 8 accumulators of ONE pixel -- MFMA row groups 2m and 2m+1 of a 32x32
+// block, i.e. couts c..c+3 (va) and c+8..c+11 (vb) on this lane, its partner lane l^32 holding c+4.. and c+12.. -- are transformed, rounded to
+// T, and lane-pair transposed (v_permlane32_swap) into one 16-byte run per lane: o = 8 consecutive couts of the output, o2 = the consumer's
+// mp_silu(scale * x) of the ROUNDED values (what its patch staging would compute), ss += sum of squares of the rounded values (pairwise
+// v_pk_fma_f32 chain, then the two halves: a fixed order shared by every flavour).  Operands: ca/cb = the 8 modulation values (EPI_EMB_SILU),
+// rw = the 16-byte residual run of this lane in the STORED layout (EPI_RESIDUAL), rs = its scale.  All flags are wave-uniform.
+template <typename T>
+__device__ __forceinline__ void epi_unit8(int epi, bool has_res, float clip, bool want_ss, bool want_o2, f32x4 va, f32x4 vb, f32x4 ca, f32x4 cb, u32x4 rw,
+                                          float rs, SiluK k_o2, u32x4& o, u32x4& o2, float& ss) {
+    typedef typename Half<T>::x4 hx4;
+    f32x2 v[4] = {{va[0], va[1]}, {va[2], va[3]}, {vb[0], vb[1]}, {vb[2], vb[3]}};
+    if (epi == EPI_EMB_SILU) {
+        const f32x2 c[4] = {{ca[0], ca[1]}, {ca[2], ca[3]}, {cb[0], cb[1]}, {cb[2], cb[3]}};
+        const SiluK k = silu_k(1.f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = silu_k2(v[q] * c[q], k);
+    } else if (epi == EPI_RESIDUAL) {
+        if (has_res) {
+            unsigned w0 = rw[0], w1 = rw[1], w2 = rw[2], w3 = rw[3];
+            swap_halves(w0, w2); swap_halves(w1, w3);
+            const hx4 ra = __builtin_bit_cast(hx4, u32x2{w0, w1}), rb = __builtin_bit_cast(hx4, u32x2{w2, w3});
+            const f32x2 r[4] = {{(float)ra[0], (float)ra[1]}, {(float)ra[2], (float)ra[3]}, {(float)rb[0], (float)rb[1]}, {(float)rb[2], (float)rb[3]}};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = v[q] + rs * r[q];
+        }
+        if (clip > 0.f) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = f32x2{__builtin_amdgcn_fmed3f(v[q].x, -clip, clip), __builtin_amdgcn_fmed3f(v[q].y, -clip, clip)};
+        }
+    }
+    const hx4 ha = {(T)v[0].x, (T)v[0].y, (T)v[1].x, (T)v[1].y};
+    const hx4 hb = {(T)v[2].x, (T)v[2].y, (T)v[3].x, (T)v[3].y};
+    const f32x2 f[4] = {{(float)ha[0], (float)ha[1]}, {(float)ha[2], (float)ha[3]}, {(float)hb[0], (float)hb[1]}, {(float)hb[2], (float)hb[3]}};
+    if (want_ss) {
+        f32x2 s2 = f[0] * f[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) s2 = f[q] * f[q] + s2;
+        ss += s2.x + s2.y;
+    }
+    {
+        const u32x2 pa = __builtin_bit_cast(u32x2, ha), pb = __builtin_bit_cast(u32x2, hb);
+        unsigned a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+        swap_halves(a0, b0); swap_halves(a1, b1);
+        o = u32x4{a0, a1, b0, b1};
+    }
+    if (want_o2) {
+        f32x2 g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = silu_k2(f[q], k_o2);
+        const hx4 ga = {(T)g[0].x, (T)g[0].y, (T)g[1].x, (T)g[1].y}, gb = {(T)g[2].x, (T)g[2].y, (T)g[3].x, (T)g[3].y};
+        const u32x2 qa = __builtin_bit_cast(u32x2, ga), qb = __builtin_bit_cast(u32x2, gb);
+        unsigned c0 = qa[0], c1 = qa[1], d0 = qb[0], d1 = qb[1];
+        swap_halves(c0, d0); swap_halves(c1, d1);
+        o2 = u32x4{c0, c1, d0, d1};
+    }
 }
 
 // Pixel owned by lane (l31) of the 32-pixel MFMA fragment that starts at tile-linear pixel q0 (a multiple of 32).

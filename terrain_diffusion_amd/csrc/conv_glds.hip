@@ -385,54 +385,48 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
             const int cobase = co0 + wn * WN + 4 * lh;
             const int sp = (p.epi == EPI_RESIDUAL && p.res) ? src_pixel(n, y, x, p.res_Hs, p.res_Ws, p.res_resample) : 0;
             if (wide) {
+                // units of 8 couts (shared arithmetic: epi_unit8); the operand of unit u+1 is requested before unit u is computed
                 const size_t pix = ((size_t)n * p.H + y) * p.W + x;
                 T* orow = (T*)p.out + pix * p.out_cstride + co0 + wn * WN + 8 * lh;
                 const T* rrow = (const T*)p.res + (size_t)sp * p.res_cstride + co0 + wn * WN + 8 * lh;
                 const float* crow = p.cvec + (size_t)n * p.cvec_stride + cobase;
                 const float rs = p.res_scale * rn;
+                const bool has_res = p.epi == EPI_RESIDUAL && p.res != nullptr, want_ss = p.out_sumsq != nullptr, want_o2 = p.out2 != nullptr;
+                const SiluK k_o2 = silu_k(p.out2_scale);
+                constexpr int NU = NT * 2;
+                f32x4 ca[2] = {}, cb[2] = {};
+                u32x4 rw[2] = {};
+                auto fetch = [&](int u, int s_) {
+                    const int j = u >> 1, m = u & 1;
+                    const bool in = co0 + wn * WN + j * 32 < p.Cout;
+#ifdef TD_ABL_EPI_NOLD  // tools/conv_bench.hip ablations of the epilogue: operand loads / arithmetic / stores removed one at a time
+                    (void)in; ca[s_] = f32x4{1.f, 1.f, 1.f, 1.f}; cb[s_] = ca[s_]; rw[s_] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#else
+                    if (p.epi == EPI_EMB_SILU) { ca[s_] = *(const f32x4*)(crow + (in ? j * 32 + m * 16 : 0)); cb[s_] = *(const f32x4*)(crow + (in ? j * 32 + m * 16 : 0) + 8); }
+                    else if (has_res) rw[s_] = *(const u32x4*)(rrow + (in ? j * 32 + m * 16 : 0));
+#endif
+                };
+                fetch(0, 0);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
+                for (int u = 0; u < NU; ++u) {
+                    const int j = u >> 1, m = u & 1, s_ = u & 1;
+                    if (u + 1 < NU) fetch(u + 1, s_ ^ 1);
                     if (co0 + wn * WN + j * 32 >= p.Cout) continue;
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) {  // row groups 2m, 2m+1
-                        f32x4 va = {acc[i][j][8 * m + 0], acc[i][j][8 * m + 1], acc[i][j][8 * m + 2], acc[i][j][8 * m + 3]};
-                        f32x4 vb = {acc[i][j][8 * m + 4], acc[i][j][8 * m + 5], acc[i][j][8 * m + 6], acc[i][j][8 * m + 7]};
-                        if (p.epi == EPI_EMB_SILU) {
-                            const f32x4 ca = *(const f32x4*)(crow + j * 32 + m * 16), cb = *(const f32x4*)(crow + j * 32 + m * 16 + 8);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { va[e] = Elem<T>::silu(va[e] * ca[e]); vb[e] = Elem<T>::silu(vb[e] * cb[e]); }
-                        } else if (p.epi == EPI_RESIDUAL) {
-                            if (p.res) {
-                                const u32x4 w = *(const u32x4*)(rrow + j * 32 + m * 16);
-                                unsigned w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-                                swap_halves(w0, w2); swap_halves(w1, w3);
-                                const hx4 ra = __builtin_bit_cast(hx4, u32x2{w0, w1}), rb = __builtin_bit_cast(hx4, u32x2{w2, w3});
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) { va[e] += rs * (float)ra[e]; vb[e] += rs * (float)rb[e]; }
-                            }
-                            if (p.clip > 0.f) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) { va[e] = fminf(fmaxf(va[e], -p.clip), p.clip); vb[e] = fminf(fmaxf(vb[e], -p.clip), p.clip); }
-                            }
-                        }
-                        const hx4 ha = {(T)va[0], (T)va[1], (T)va[2], (T)va[3]};
-                        const hx4 hb = {(T)vb[0], (T)vb[1], (T)vb[2], (T)vb[3]};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { const float fa = (float)ha[e], fb = (float)hb[e]; ssj[j] += fa * fa + fb * fb; }
-                        const u32x2 pa = __builtin_bit_cast(u32x2, ha), pb = __builtin_bit_cast(u32x2, hb);
-                        unsigned a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
-                        swap_halves(a0, b0); swap_halves(a1, b1);
-                        *(u32x4*)(orow + j * 32 + m * 16) = u32x4{a0, a1, b0, b1};
-                        if (p.out2) {  // the consumer's mp_silu(scale * x), from the rounded value (== what its patch staging would compute)
-                            hx4 ga, gb;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { ga[e] = (T)Elem<T>::silu((float)ha[e] * p.out2_scale); gb[e] = (T)Elem<T>::silu((float)hb[e] * p.out2_scale); }
-                            const u32x2 qa = __builtin_bit_cast(u32x2, ga), qb = __builtin_bit_cast(u32x2, gb);
-                            unsigned c0 = qa[0], c1 = qa[1], d0 = qb[0], d1 = qb[1];
-                            swap_halves(c0, d0); swap_halves(c1, d1);
-                            *(u32x4*)((T*)p.out2 + (orow - (T*)p.out) + j * 32 + m * 16) = u32x4{c0, c1, d0, d1};
-                        }
-                    }
+                    const f32x4 va = {acc[i][j][8 * m + 0], acc[i][j][8 * m + 1], acc[i][j][8 * m + 2], acc[i][j][8 * m + 3]};
+                    const f32x4 vb = {acc[i][j][8 * m + 4], acc[i][j][8 * m + 5], acc[i][j][8 * m + 6], acc[i][j][8 * m + 7]};
+                    u32x4 o, o2;
+#ifdef TD_ABL_EPI_NOVALU
+                    o = u32x4{__builtin_bit_cast(unsigned, va[0]) ^ rw[s_][0], __builtin_bit_cast(unsigned, va[1]) ^ __builtin_bit_cast(unsigned, ca[s_][0]), __builtin_bit_cast(unsigned, vb[0]), __builtin_bit_cast(unsigned, vb[1])};
+                    o2 = u32x4{__builtin_bit_cast(unsigned, va[2]), __builtin_bit_cast(unsigned, va[3]), __builtin_bit_cast(unsigned, vb[2]), __builtin_bit_cast(unsigned, vb[3]) ^ __builtin_bit_cast(unsigned, cb[s_][0])};
+#else
+                    epi_unit8<T>(p.epi, has_res, p.clip, want_ss, want_o2, va, vb, ca[s_], cb[s_], rw[s_], rs, k_o2, o, o2, ssj[j]);
+#endif
+#ifdef TD_ABL_EPI_NOST
+                    if (o[0] == 0x12345678u && o2[1] == 0x9abcdef0u && (!want_o2 || o2[0] == 77u)) *(u32x4*)(orow + j * 32 + m * 16) = o;
+#else
+                    *(u32x4*)(orow + j * 32 + m * 16) = o;
+                    if (want_o2) *(u32x4*)((T*)p.out2 + (orow - (T*)p.out) + j * 32 + m * 16) = o2;
+#endif
                 }
             } else {
 #pragma unroll

@@ -289,8 +289,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
     auto epilogue = [&]() {
         constexpr int NU = MT * NT * 2;
         const int co0 = ent * BN;
-        f32x4 ca[2], cb[2];
-        u32x4 rw[2];
+        f32x4 ca[2] = {}, cb[2] = {};
+        u32x4 rw[2] = {};
         int pixv[MT]; bool okv[MT]; float rnv[MT], ssv[MT][NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -304,13 +304,15 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
             for (int j = 0; j < NT; ++j) ssv[i][j] = 0.f;
         }
         const int cobase = co0 + wn * WN + 4 * lh;
+        const bool has_res = p.epi == EPI_RESIDUAL && p.res != nullptr, want_ss = p.out_sumsq != nullptr, want_o2 = p.out2 != nullptr;
+        const SiluK k_o2 = silu_k(p.out2_scale);
         auto fetch = [&](int u, int s) {
             const int i = u / (NT * 2), j = (u / 2) % NT, m = u % 2;
             const bool in = co0 + wn * WN + j * 32 < p.Cout;
             if (p.epi == EPI_EMB_SILU) {
                 const float* crow = p.cvec + (size_t)en0 * p.cvec_stride + (in ? cobase + j * 32 + m * 16 : 0);
                 ca[s] = *(const f32x4*)crow; cb[s] = *(const f32x4*)(crow + 8);
-            } else if (p.epi == EPI_RESIDUAL && p.res) {
+            } else if (has_res) {
                 int img, ty, tx;
                 frag_pixel<TW, TPIX>(wm * WM + i * 32, l31, img, ty, tx);
                 const int sp = okv[i] ? src_pixel(en0, ey0 + ty, ex0 + tx, p.res_Hs, p.res_Ws, p.res_resample) : 0;
@@ -323,43 +325,13 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p) {
             const int i = u / (NT * 2), j = (u / 2) % NT, m = u % 2, s = u & 1;
             if (u + 1 < NU) fetch(u + 1, s ^ 1);
             if (co0 + wn * WN + j * 32 < p.Cout) {
-                f32x4 va = {acc[i][j][8 * m + 0], acc[i][j][8 * m + 1], acc[i][j][8 * m + 2], acc[i][j][8 * m + 3]};
-                f32x4 vb = {acc[i][j][8 * m + 4], acc[i][j][8 * m + 5], acc[i][j][8 * m + 6], acc[i][j][8 * m + 7]};
-                if (p.epi == EPI_EMB_SILU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { va[e] = Elem<T>::silu(va[e] * ca[s][e]); vb[e] = Elem<T>::silu(vb[e] * cb[s][e]); }
-                } else if (p.epi == EPI_RESIDUAL) {
-                    if (p.res) {
-                        const float rs = p.res_scale * rnv[i];
-                        unsigned w0 = rw[s][0], w1 = rw[s][1], w2 = rw[s][2], w3 = rw[s][3];
-                        swap_halves(w0, w2); swap_halves(w1, w3);
-                        const hx4 ra = __builtin_bit_cast(hx4, u32x2{w0, w1}), rb4 = __builtin_bit_cast(hx4, u32x2{w2, w3});
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { va[e] += rs * (float)ra[e]; vb[e] += rs * (float)rb4[e]; }
-                    }
-                    if (p.clip > 0.f) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { va[e] = fminf(fmaxf(va[e], -p.clip), p.clip); vb[e] = fminf(fmaxf(vb[e], -p.clip), p.clip); }
-                    }
-                }
-                const hx4 ha = {(T)va[0], (T)va[1], (T)va[2], (T)va[3]};
-                const hx4 hb = {(T)vb[0], (T)vb[1], (T)vb[2], (T)vb[3]};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float fa = (float)ha[e], fb = (float)hb[e]; ssv[i][j] += fa * fa + fb * fb; }
-                const u32x2 pa = __builtin_bit_cast(u32x2, ha), pb2 = __builtin_bit_cast(u32x2, hb);
-                unsigned a0 = pa[0], a1 = pa[1], b0 = pb2[0], b1 = pb2[1];
-                swap_halves(a0, b0); swap_halves(a1, b1);
+                const f32x4 va = {acc[i][j][8 * m + 0], acc[i][j][8 * m + 1], acc[i][j][8 * m + 2], acc[i][j][8 * m + 3]};
+                const f32x4 vb = {acc[i][j][8 * m + 4], acc[i][j][8 * m + 5], acc[i][j][8 * m + 6], acc[i][j][8 * m + 7]};
+                u32x4 o, o2;
+                epi_unit8<T>(p.epi, has_res, p.clip, want_ss, want_o2, va, vb, ca[s], cb[s], rw[s], p.res_scale * rnv[i], k_o2, o, o2, ssv[i][j]);
                 const size_t oo = (size_t)pixv[i] * p.out_cstride + co0 + wn * WN + 8 * lh + j * 32 + m * 16;
-                if (okv[i]) *(u32x4*)((T*)p.out + oo) = u32x4{a0, a1, b0, b1};
-                if (p.out2) {  // the consumer's mp_silu(scale * x), from the rounded value (== what its patch staging would compute)
-                    hx4 ga, gb;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { ga[e] = (T)Elem<T>::silu((float)ha[e] * p.out2_scale); gb[e] = (T)Elem<T>::silu((float)hb[e] * p.out2_scale); }
-                    const u32x2 qa = __builtin_bit_cast(u32x2, ga), qb = __builtin_bit_cast(u32x2, gb);
-                    unsigned c0 = qa[0], c1 = qa[1], d0 = qb[0], d1 = qb[1];
-                    swap_halves(c0, d0); swap_halves(c1, d1);
-                    if (okv[i]) *(u32x4*)((T*)p.out2 + oo) = u32x4{c0, c1, d0, d1};
-                }
+                if (okv[i]) *(u32x4*)((T*)p.out + oo) = o;
+                if (want_o2 && okv[i]) *(u32x4*)((T*)p.out2 + oo) = o2;
             }
             __builtin_amdgcn_sched_barrier(0);
         }

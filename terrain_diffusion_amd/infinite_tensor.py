@@ -138,8 +138,29 @@ class InfiniteTensor:
         assert len(output_window.size) == len(self.shape)
         self.tile_store = tile_store if tile_store is not None else MemoryTileStore()
         self.tensor_id = tensor_id if tensor_id is not None else f"tensor{id(self)}"
-        self.batch_size = batch_size
+        # batch_size: None (f takes one window), an int (f takes lists of up to that many windows), or a sequence of ALLOWED batch sizes
+        # (WorldPipeline's latents_batch_size, world_pipeline.py:289: missing windows are cut greedily into those sizes, which bounds the
+        # number of distinct batch shapes the engine has to plan for)
+        if batch_size is not None and not isinstance(batch_size, (int, np.integer)):
+            self.batch_sizes = sorted({int(b) for b in batch_size if int(b) > 0})
+            self.batch_size = self.batch_sizes[-1]
+        else:
+            self.batch_sizes = None
+            self.batch_size = batch_size
         self.dtype = dtype
+
+    def _chunks(self, missing):
+        if not self.batch_size:
+            return [[c] for c in missing]
+        if not self.batch_sizes:
+            return [missing[b0:b0 + self.batch_size] for b0 in range(0, len(missing), self.batch_size)]
+        out, b0 = [], 0
+        while b0 < len(missing):
+            left = len(missing) - b0
+            n = max([b for b in self.batch_sizes if b <= left] or [min(self.batch_sizes[0], left)])
+            out.append(missing[b0:b0 + n])
+            b0 += n
+        return out
 
     # ------------------------------------------------------------------ region bookkeeping
     def _normalize_slices(self, idx):
@@ -171,6 +192,28 @@ class InfiniteTensor:
         return list(itertools.product(*ranges))
 
     # ------------------------------------------------------------------ evaluation
+    def prefetch(self, regions):
+        """Computes every missing window that intersects any of `regions` = [(lo, hi), ...] in as few batches as the batch size allows
+        (and, recursively, the upstream windows those need).  Purely an ordering hint: values do not depend on it."""
+        ctxs = set()
+        for lo, hi in regions:
+            ctxs.update(self._windows_for(lo, hi))
+        self._ensure(sorted(ctxs))
+
+    def _prefetch_upstream(self, missing):
+        """A request that misses several windows asks every upstream tensor for the UNION of their argument regions first, so that the
+        upstream stage sees one large batch instead of one small batch per window of this stage (the reference's graph evaluates the
+        dependencies window by window; on a 256-CU device the batch is what fills the chip)."""
+        if len(missing) < 2:
+            return
+        for a, aw in zip(self.args, self.args_windows):
+            if hasattr(a, "prefetch"):
+                regs = []
+                for c in missing:
+                    b = aw.bounds(c)
+                    regs.append(([l for l, _ in b], [h for _, h in b]))
+                a.prefetch(regs)
+
     def _ensure(self, ctxs):
         """Computes (batched) every window of `ctxs` that is not cached; returns {ctx: output}."""
         out, missing = {}, []
@@ -180,10 +223,9 @@ class InfiniteTensor:
                 missing.append(c)
             else:
                 out[c] = t
+        self._prefetch_upstream(missing)
         if missing:
-            bs = self.batch_size or 1
-            for b0 in range(0, len(missing), bs if self.batch_size else 1):
-                chunk = missing[b0:b0 + (bs if self.batch_size else 1)]
+            for chunk in self._chunks(missing):
                 arg_lists = []
                 for a, aw in zip(self.args, self.args_windows):
                     sl = []
@@ -258,9 +300,8 @@ class DeviceWindowTensor(InfiniteTensor):
                 missing.append(c)
             else:
                 out[c] = t
-        bs = self.batch_size or len(missing) or 1
-        for b0 in range(0, len(missing), bs):
-            chunk = missing[b0:b0 + bs]
+        self._prefetch_upstream(missing)
+        for chunk in (self._chunks(missing) if self.batch_size else [missing] if missing else []):
             arg_lists = [[a[tuple(slice(l, h) for l, h in aw.bounds(c))] for c in chunk] for a, aw in zip(self.args, self.args_windows)]
             res = self.f(list(chunk), *arg_lists)
             assert res.is_cuda and tuple(res.shape) == (len(chunk), self.channels, self.tile, self.tile), (tuple(res.shape), res.device)

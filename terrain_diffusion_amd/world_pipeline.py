@@ -154,7 +154,7 @@ class WorldPipeline:
     def _build_hierarchy(self):
         resident = self.device_resident and self.caching_strategy == "direct"
         kw = dict(tile_store=self.tile_store, device_resident=resident)
-        bs = self.latents_batch_size
+        bs = tuple(self._batch_sizes)   # allowed batch sizes; the stages cut their missing windows greedily into these
         sch = EDMDPMSolverMultistepScheduler(sigma_min=0.002, sigma_max=80, sigma_data=0.5)
         self.coarse = stages.build_coarse_stage(self.coarse_model, sch, seed=self.seed, cond_map_fn=self._conditioning_model_input,
                                                 coarse_means=self.kwargs["coarse_means"], coarse_stds=self.kwargs["coarse_stds"], cond_snr=self.kwargs["cond_snr"],
@@ -163,7 +163,7 @@ class WorldPipeline:
         self.latents = stages.build_latent_stage(self.base_model, seed=self.seed, coarse=self.coarse, histogram_raw=[self.kwargs["histogram_raw"]], T=self.T,
                                                  onestep_latent=self.onestep_latent, batch_size=bs, **kw)
         self.residual = stages.build_decoder_stage(self.decoder_model, self.latents, seed=self.seed, tile_size=self.decoder_tile_size,
-                                                   tile_stride=self.decoder_tile_stride, latent_compression=self.latent_compression, batch_size=max(1, min(4, bs)), **kw)
+                                                   tile_stride=self.decoder_tile_stride, latent_compression=self.latent_compression, batch_size=tuple(b for b in bs if b <= 4) or (1,), **kw)
 
     def rebuild(self):
         if self.tile_store is None:

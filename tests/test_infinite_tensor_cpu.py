@@ -81,6 +81,33 @@ def test_batched_f_args_windows_and_offset():
     assert sum(seen) == 4 and max(seen) == 3
 
 
+def test_upstream_prefetch_batches_the_union_and_allowed_batch_sizes():
+    """A request that misses several windows asks its upstream tensor for the union of their argument regions first: the upstream stage sees
+    one big batch (cut into the ALLOWED sizes, WorldPipeline's latents_batch_size semantics) instead of one small batch per downstream chunk;
+    values are the same as without the hint."""
+    def make(prefetch):
+        calls = []
+
+        def f_base(ctxs):
+            calls.append(len(ctxs))
+            return [torch.full((1, 4, 4), float(c[1] * 10 + c[2])) for c in ctxs]
+
+        base = InfiniteTensor(shape=(1, None, None), f=f_base, output_window=TensorWindow((1, 4, 4), (1, 4, 4)), tensor_id="b", batch_size=(1, 2, 4, 8))
+        if not prefetch:
+            base.prefetch = None  # hasattr() is still true, so shadow the hook with a no-op
+            base.prefetch = lambda regions: None
+        top = InfiniteTensor(shape=(1, None, None), f=lambda ctxs, prevs: [p.sum() * torch.ones(1, 4, 4) for p in prevs],
+                             output_window=TensorWindow((1, 4, 4), (1, 4, 4)), args=(base,), args_windows=(TensorWindow((1, 8, 8), (1, 4, 4), (0, -2, -2)),),
+                             tensor_id="t", batch_size=2)
+        return top, calls
+    top, calls = make(True)
+    got = top[:, 0:12, 0:12]                 # 9 top windows, each needs 3x3 base windows: the union is 5x5 = 25 base windows
+    assert sum(calls) == 25 and calls == [8, 8, 8, 1], calls
+    top2, calls2 = make(False)
+    assert torch.equal(top2[:, 0:12, 0:12], got)
+    assert sum(calls2) == 25 and max(calls2) <= 8 and len(calls2) > len(calls)
+
+
 def test_lru_eviction_recomputes_identically():
     store = MemoryTileStore(cache_size_bytes=3 * 4 * 4 * 4)   # room for 3 windows
     rngs = {}
