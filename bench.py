@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--tiles-per-step", type=int, default=64)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"])
     ap.add_argument("--edm-steps", type=int, default=20)
+    ap.add_argument("--cache-mib", type=int, default=100, help="cascade workload: window-cache cap in MiB (default = the reference's cache_limit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-tile latency leg (keeps rocprofv3 counter passes to the batched steps only)")

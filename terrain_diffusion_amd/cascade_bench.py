@@ -30,7 +30,7 @@ def run_cascade(args, eng, dev, rank, world):
         m = td.EDMUnet2D(**cfg, dtype=dtype, device=dev)
         models.append(m.load_state_dict(synthetic_state_dict(m, seed=seed)))
     R, Q = 3072, 1024                       # region and request size in decoded pixels (3 x 3 requests per step)
-    cache = 100 * 2 ** 20                   # the reference's default cache_limit (world_pipeline.py:311); one step produces ~150 MiB of windows -> streaming eviction
+    cache = int(getattr(args, 'cache_mib', 100)) * 2 ** 20   # default 100 MiB = the reference's cache_limit (world_pipeline.py:311); one step produces ~150 MiB of windows -> streaming eviction
     world_p = td.WorldPipeline.from_models(*models, seed=4242 + rank, dtype=dtype, device=dev, cache_limit=cache, latents_batch_size=(1, 2, 4, 8, 16, 32, 64)).bind()
 
     def one_step(i):

@@ -522,7 +522,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
     // every option the plan builder reads is part of the cache key (a plan built under other options must never be reused)
     static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn", "pp",
                                                "pp_min_items_per_cu", "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
-                                               "bn128_min_wgs", "attn_mfma"};
+                                               "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups"};
     std::string key = std::to_string(N) + "_" + std::to_string(H) + "_" + std::to_string(W);
     for (const char* o : kPlanOptions) key += "_" + std::to_string((long long)u->eng->option(o, -7));
     auto it = u->plans.find(key);
@@ -627,7 +627,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
                 // too few workgroups to give every SIMD two waves (8x8 level of a 64-tile batch, small batches): split K, the fp32
                 // partials are summed in fixed order by conv_splitk_reduce_kernel (not in batch_invariant mode: the K order changes)
                 const int64_t wgs = mt2 * p.n_ntiles, slots = variant ? 512 : 256;
-                if (!inv && use_splitk && u->eng->option("glds_splitk", 1) && kgroups >= 4 && wgs * 2 <= slots)
+                if (!inv && use_splitk && u->eng->option("glds_splitk", 1) && kgroups >= u->eng->option("glds_splitk_from_groups", 2) && wgs * 2 <= slots)
                     p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(u->eng->option("glds_splitk_max", 32), kgroups / std::max<int64_t>(1, u->eng->option("glds_splitk_min_groups", 1))), slots / wgs);
                 // persistent ping-pong flavour (conv_pp.hip): 3x3-only convs on >= 16-wide maps whose work items fill the chip at least
                 // "pp_min_items_per_cu" times; bit-identical to the LDS-DMA flavour (same K order, same MFMA), so the choice may depend on the batch
