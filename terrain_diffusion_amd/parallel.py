@@ -102,6 +102,9 @@ def exchange_windows(plan: ShardPlan, rank, my_tiles, group=None):
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        if my_tiles.is_cuda:
+            # RCCL's wait() only orders the transfer before later work on torch's CURRENT stream; the engine blends on its own stream
+            torch.cuda.current_stream(my_tiles.device).synchronize()
     for s, (buf, wins) in recv_bufs.items():
         for i, w in enumerate(wins):
             have[w] = buf[i]
