@@ -26,6 +26,9 @@ class EDMUnet2D:
             raise NotImplementedError("block_kwargs / encode_only / disable_out_gain are not on the accelerated path")
         if fourier_scale != "pos":
             raise NotImplementedError("only fourier_scale='pos' (the released configs) is supported")
+        if noise_emb_dims is not None and int(noise_emb_dims) == 0:
+            # edm_unet.py:49,87-90: 0 DISABLES the noise input; the engine's embedding kernel always has one (None = model_channels)
+            raise NotImplementedError("noise_emb_dims=0 (noise input disabled) is not on the accelerated path")
         mults = list(model_channel_mults or [1, 2, 3, 4])
         lpb = [layers_per_block] * len(mults) if isinstance(layers_per_block, int) else list(layers_per_block)
         conds = [list(c) for c in conditional_inputs]
@@ -91,6 +94,9 @@ class EDMUnet2D:
         unexpected = [k for k in state_dict if k not in exp and not k.startswith("logvar_")]
         if strict and (missing or unexpected):
             raise KeyError(f"state dict mismatch: missing {missing[:5]} unexpected {unexpected[:5]}")
+        if missing:
+            # strict=False tolerates UNEXPECTED keys (as torch does); the engine has no initialiser for a parameter the checkpoint lacks
+            raise ValueError(f"state dict lacks {len(missing)} parameter(s) the model needs, e.g. {missing[:5]}: the engine cannot run on uninitialised weights")
         check(lib().td_unet_set_prefolded(self._h, int(fold == "reference")))
         for k, shape in exp.items():
             w = torch.as_tensor(state_dict[k]).detach().to("cpu", torch.float32).contiguous()
@@ -107,7 +113,25 @@ class EDMUnet2D:
             check(lib().td_unet_set_param(self._h, k.encode(), C.c_void_p(w.data_ptr()), w.numel()))
         check(lib().td_unet_finalize(self._h))
         self._finalized = True
+        # the caller's (raw, un-folded) tensors are kept by reference for state_dict() / save_pretrained(): the engine only holds packed weights
+        self._state = {k: state_dict[k] for k in state_dict if k in exp or k.startswith("logvar_")}
         return self
+
+    def state_dict(self):
+        """The parameters this model was loaded from, under the reference's names (raw values, as a checkpoint holds them)."""
+        if not self._finalized:
+            raise RuntimeError("load_state_dict first")
+        return dict(self._state)
+
+    def save_pretrained(self, save_directory, **_ignored):
+        """diffusers ModelMixin layout (what world_pipeline.py:500-518 writes per sub-model and from_pretrained reads back):
+        <dir>/config.json with the constructor arguments + <dir>/diffusion_pytorch_model.safetensors."""
+        from safetensors.torch import save_file
+        os.makedirs(save_directory, exist_ok=True)
+        with open(os.path.join(save_directory, "config.json"), "w") as f:
+            json.dump(dict(self.config, _class_name="EDMUnet2D"), f, indent=2, sort_keys=True)
+        save_file({k: torch.as_tensor(v).detach().to("cpu", torch.float32).contiguous() for k, v in self.state_dict().items()},
+                  os.path.join(save_directory, "diffusion_pytorch_model.safetensors"))
 
     @classmethod
     def from_pretrained(cls, path, *, dtype="bf16", device="cuda"):
@@ -136,6 +160,10 @@ class EDMUnet2D:
         t = f32(noise_labels, "cpu").flatten()
         if t.numel() == 1 and n > 1:
             t = t.expand(n).contiguous()
+        if t.numel() != n:
+            raise ValueError(f"noise_labels has {t.numel()} entries for a batch of {n} (expected 1 or {n})")
+        if x.shape[1] != self.config["in_channels"]:
+            raise ValueError(f"x has {x.shape[1]} channels, the model takes {self.config['in_channels']}")
         cond = self.cond_rows(conditional_inputs, n, x.device)
         out = torch.empty((n, self.config["out_channels"], H, W), dtype=torch.float32, device=x.device)
         check(lib().td_unet_forward(self._h, n, H, W, ptr(x), ptr(t), ptr(cond), ptr(out)))

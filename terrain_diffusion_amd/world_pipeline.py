@@ -109,6 +109,13 @@ class WorldPipeline:
         with open(os.path.join(save_directory, self.config_name), "w") as f:
             json.dump(dict(self._config, _class_name="WorldPipeline"), f, indent=2, sort_keys=True)
 
+    def save_pretrained(self, save_directory, **kwargs):
+        """world_pipeline.py:500-518: the pipeline's config.json + one sub-folder per model (config.json + safetensors)."""
+        self.save_config(save_directory)
+        for model, folder in ((self.coarse_model, self.COARSE_MODEL_FOLDER), (self.base_model, self.BASE_MODEL_FOLDER), (self.decoder_model, self.DECODER_MODEL_FOLDER)):
+            if model is not None:
+                model.save_pretrained(os.path.join(save_directory, folder), **kwargs)
+
     def to(self, device):
         return self
 

@@ -105,3 +105,13 @@ def test_committed_bench_line_honours_the_contract():
     assert c["kind"] == "port" and c["unit"] == "MP/s" and c["cores"] >= 1 and "sample" in c
     # value = whole-job MP per second: tiles x 0.262144 MP / step time
     assert abs(d["value"] - d["config"]["decoded_mp_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+
+
+def test_unsupported_constructor_arguments_are_refused_before_the_engine_starts():
+    """reference options the accelerated path does not carry are refused loudly (never silently remapped): block_kwargs / encode_only,
+    fourier_scale != 'pos', 'embedding' conditional inputs, and noise_emb_dims=0 (edm_unet.py:49: 0 disables the noise input)."""
+    import terrain_diffusion_amd as td
+    base = dict(image_size=64, in_channels=5, model_channels=64, conditional_inputs=[["tensor", 58, 1.0]], fourier_scale="pos")
+    for bad in (dict(noise_emb_dims=0), dict(fourier_scale=1), dict(encode_only=True), dict(conditional_inputs=[["embedding", 10, 1.0]])):
+        with pytest.raises(NotImplementedError):
+            td.EDMUnet2D(**{**base, **bad})

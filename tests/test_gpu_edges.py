@@ -195,3 +195,27 @@ def test_producer_side_activation_is_bit_identical(td):
             eng.set_option("producer_act", 1)
         assert torch.equal(a, b), dtype
         m.close()
+
+
+def test_forward_and_checkpoint_argument_validation(td):
+    """noise_labels must have 1 or n entries (the engine reads n of them), x must have in_channels channels, and a checkpoint that lacks a
+    parameter is refused even with strict=False (which, as in torch, only tolerates unexpected keys)."""
+    from oracle.unet import synth_state_dict, tiny_config
+    cfg = tiny_config(64, 1)
+    sd = synth_state_dict(cfg, seed=3)
+    m = td.EDMUnet2D(**cfg, dtype="fp32")
+    short = dict(sd)
+    short.pop(next(k for k in sd if k.endswith("conv_res0.weight")))
+    with pytest.raises(KeyError):
+        m.load_state_dict(short)
+    with pytest.raises(ValueError):
+        m.load_state_dict(short, strict=False)
+    m.load_state_dict({**sd, "some_extra_buffer": torch.zeros(3)}, strict=False)
+    x = torch.randn(3, cfg["in_channels"], 64, 64, device="cuda")
+    c = torch.randn(3, 58, device="cuda")
+    assert m(x, torch.tensor([0.3]), [c]).shape == (3, cfg["out_channels"] if cfg.get("out_channels") else cfg["in_channels"], 64, 64)
+    with pytest.raises(ValueError):
+        m(x, torch.tensor([0.3, 0.4]), [c])
+    with pytest.raises(ValueError):
+        m(x[:, :3], torch.tensor([0.3]), [c])
+    m.close()

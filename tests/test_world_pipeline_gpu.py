@@ -116,3 +116,29 @@ def test_world_pipeline_persistent_store_and_wire_format(td, models, tmp_path):
 def _world_indirect(td, models, path):
     return td.WorldPipeline.from_models(*models, seed=4242, decoder_tile_size=64, decoder_tile_stride=48, latents_batch_size=16,
                                         caching_strategy="indirect").bind(path)
+
+
+def test_save_pretrained_round_trip(td, models, tmp_path):
+    """save_pretrained writes the reference's layout (world_pipeline.py:500-518: config.json + coarse_model/ base_model/ decoder_model/, each a
+    config.json + one safetensors state dict under the reference's parameter names); from_pretrained on that directory rebuilds a pipeline
+    that serves the same bytes."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    w = _world(td, models)
+    box = (5, -9, 69, 71)
+    ref = w.get(*box)
+    root = str(tmp_path / "pipe")
+    w.save_pretrained(root)
+    assert sorted(os.listdir(root)) == ["base_model", "coarse_model", "config.json", "decoder_model"]
+    cfg = json.load(open(os.path.join(root, "config.json")))
+    assert cfg["_class_name"] == "WorldPipeline" and cfg["decoder_tile_size"] == 64 and "seed" not in cfg
+    sd = load_file(os.path.join(root, "base_model", "diffusion_pytorch_model.safetensors"))
+    assert set(models[1].expected_parameters()) <= set(sd) and all(v.dtype == torch.float32 for v in sd.values())
+    w2 = td.WorldPipeline.from_pretrained(root, seed=4242, latents_batch_size=16, dtype=None).bind()
+    got = w2.get(*box)
+    assert torch.equal(got["elev"], ref["elev"]) and torch.equal(got["climate"], ref["climate"])
+    w2.close()
+    for m in (w2.coarse_model, w2.base_model, w2.decoder_model):
+        m.close()
+    w.close()
