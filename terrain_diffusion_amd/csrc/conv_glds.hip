@@ -502,8 +502,14 @@ static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
 //               ~91 KB LDS -> one workgroup per CU
 //   1 "small" : 4 waves, 128-pixel tile (8x16, narrow maps 8x8 x 2 images), bn 128 -> waves 2x2 (64 px x 64 co), bn 96 -> 4x1 (32 px x 96 co);
 //               ~71 KB LDS -> two independent workgroups per CU whose prologues / epilogues / barrier stalls overlap
+//   bn 64 (16-wide maps only): big = 8 waves 8x1 (32 px x 64 co), small = 4 waves 4x1 on 128 pixels (32 px x 64 co).  For the 64-cout-granular
+//   layers (the decoder's 64 / 320-channel levels, 5-channel output convs) that would otherwise fall to the per-tap flavour.
 template <typename T>
 static hipError_t launch_conv_glds_t(const ConvParams& p, bool narrow, int bn, int variant, hipStream_t st) {
+    if (bn == 64) {
+        if (narrow) return hipErrorInvalidValue;
+        return variant == 1 ? launch_glds_cfg<T, 8, 16, 1, 64, 4, 1>(p, st) : launch_glds_cfg<T, 16, 16, 1, 64, 8, 1>(p, st);
+    }
     if (variant == 1) {
         if (!narrow) return bn == 128 ? launch_glds_cfg<T, 8, 16, 1, 128, 2, 2>(p, st) : launch_glds_cfg<T, 8, 16, 1, 96, 4, 1>(p, st);
         return bn == 128 ? launch_glds_cfg<T, 8, 8, 2, 128, 2, 2>(p, st) : launch_glds_cfg<T, 8, 8, 2, 96, 4, 1>(p, st);
@@ -514,7 +520,7 @@ static hipError_t launch_conv_glds_t(const ConvParams& p, bool narrow, int bn, i
 
 // dtype: 1 bf16, 2 fp16 (this flavour has no fp32 form)
 hipError_t launch_conv_glds(const ConvParams& p, int dtype, bool narrow, int bn, int variant, hipStream_t st) {
-    if (bn != 96 && bn != 128) return hipErrorInvalidValue;
+    if (bn != 64 && bn != 96 && bn != 128) return hipErrorInvalidValue;
     return dtype == 2 ? launch_conv_glds_t<_Float16>(p, narrow, bn, variant, st) : launch_conv_glds_t<__bf16>(p, narrow, bn, variant, st);
 }
 

@@ -522,7 +522,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
     // every option the plan builder reads is part of the cache key (a plan built under other options must never be reused)
     static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn", "pp",
                                                "pp_min_items_per_cu", "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
-                                               "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups"};
+                                               "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups"};
     std::string key = std::to_string(N) + "_" + std::to_string(H) + "_" + std::to_string(W);
     for (const char* o : kPlanOptions) key += "_" + std::to_string((long long)u->eng->option(o, -7));
     auto it = u->plans.find(key);
@@ -606,15 +606,21 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
             const int TW2 = op.narrow ? 8 : 16;
             const bool c128 = cw.cout_pad % 128 == 0, c96 = cw.cout_pad % 96 == 0;
             auto tiles = [&](int TH, int NIMG) { return (int64_t)((w + TW2 - 1) / TW2) * ((h + TH - 1) / TH) * ((N + NIMG - 1) / NIMG); };
-            auto pick_bn = [&](int64_t mt) { return (c128 && (mt * (cw.cout_pad / 128) >= 512 || !c96)) ? 128 : (c96 ? 96 : 0); };
+            // couts in 128s / 96s; 64s (cout_pad is always a multiple of 64) on 16-wide maps for the layers neither divides: the decoder's 64- and
+            // 320-channel levels and the few-channel output convs, which would otherwise run on the per-tap flavour (option "glds_bn64")
+            const bool c64 = !op.narrow && u->eng->option("glds_bn64", 1) != 0;
+            auto pick_bn = [&](int64_t mt) { return (c128 && (mt * (cw.cout_pad / 128) >= 512 || !c96)) ? 128 : (c96 ? 96 : (c64 ? 64 : 0)); };
             const int64_t mt_big = tiles(op.narrow ? 8 : 16, op.narrow ? 4 : 1), mt_small = tiles(8, op.narrow ? 2 : 1);
             int variant = 0, bn2 = pick_bn(mt_big);
             if (bn2 && mt_big * (cw.cout_pad / bn2) < 1024) { variant = 1; bn2 = pick_bn(mt_small); }
+            // short K loops (<= "glds_small_max_groups" K-groups): prologue and epilogue dominate a workgroup's life, two independent small
+            // workgroups per CU overlap them (decoder 512x512 / 256x256 levels: 64- and 128-channel convs)
+            if (bn2 && !op.narrow && kgroups <= u->eng->option("glds_small_max_groups", 6)) { variant = 1; bn2 = pick_bn(mt_small); }
             // test hooks: "glds_variant" = 0 (big) / 1 (small) and "glds_bn" = 96 / 128 force the tile shape wherever it is legal
             // (tests assert that every legal shape gives bit-identical results: same K order, same MFMA)
             const int64_t fv = u->eng->option("glds_variant", -1), fbn = u->eng->option("glds_bn", 0);
             if (bn2 && (fv == 0 || fv == 1)) { variant = (int)fv; bn2 = pick_bn(variant ? mt_small : mt_big); }
-            if (bn2 && ((fbn == 128 && c128) || (fbn == 96 && c96))) bn2 = (int)fbn;
+            if (bn2 && ((fbn == 128 && c128) || (fbn == 96 && c96) || (fbn == 64 && c64))) bn2 = (int)fbn;
             const int64_t mt2 = variant ? mt_small : mt_big;
             // "batch_invariant": kernel flavour and K order do not depend on the batch size (no split-K, LDS-DMA flavour whenever it
             // applies), so a window's result is bit-identical whatever other windows share its batch / GPU.
@@ -635,7 +641,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out) {
                 for (int i = 0; i < p.nseg; ++i) all9 = all9 && p.seg[i].taps == 9;
                 const int64_t pp_items = tiles(16, 1) * (cw.cout_pad / bn2);
                 const int64_t pp_mode = u->eng->option("pp", 0);  // 0 off (default: measured on par with the LDS-DMA flavour), 1 auto, 2 wherever legal
-                if (pp_mode && all9 && !op.narrow && !out_f32 && cw.cout % 8 == 0 && p.ksplit == 1 &&
+                if (pp_mode && bn2 != 64 && all9 && !op.narrow && !out_f32 && cw.cout % 8 == 0 && p.ksplit == 1 &&
                     (pp_mode == 2 || pp_items >= u->eng->option("pp_min_items_per_cu", 2) * (int64_t)u->eng->n_cus)) {
                     op.flavor = 3; op.glds_variant = 0;
                     p.tiles_x = (w + 15) / 16; p.tiles_y = (h + 15) / 16; p.img_groups = N;
