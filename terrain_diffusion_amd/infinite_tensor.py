@@ -155,11 +155,40 @@ class InfiniteTensor:
         if not self.batch_sizes:
             return [missing[b0:b0 + self.batch_size] for b0 in range(0, len(missing), self.batch_size)]
         out, b0 = [], 0
-        while b0 < len(missing):
-            left = len(missing) - b0
-            n = max([b for b in self.batch_sizes if b <= left] or [min(self.batch_sizes[0], left)])
-            out.append(missing[b0:b0 + n])
+        for n in self._plan_batches(len(missing)):
+            out.append(missing[b0:b0 + n])   # the last chunk of a padded plan is shorter than its batch: the caller pads it (DeviceWindowTensor)
             b0 += n
+        return out
+
+    # cost model of one batched call: fixed + per-window (in units of one window); None = greedy largest-allowed-size cut, no padding
+    batch_cost_fixed = None
+
+    def _plan_batches(self, n):
+        """Sizes of the batched calls for n missing windows, from the allowed sizes.  Without a cost model: greedily the largest allowed size
+        that fits.  With one (batch_cost_fixed = cost of a call in window-equivalents; engine-backed tensors): the cheapest cover, where the
+        last call may be PADDED up to an allowed size with repeats of its last window -- a batch of 2 costs almost as much as a batch of 8 on a
+        256-CU device, so 50 windows are one padded batch of 64 rather than 32 + 16 + 2."""
+        S = self.batch_sizes
+        if self.batch_cost_fixed is None:
+            out, left = [], n
+            while left > 0:
+                b = max([b for b in S if b <= left] or [min(S[0], left)])
+                out.append(b)
+                left -= b
+            return out
+        cost = lambda b: self.batch_cost_fixed + b
+        best = [0.0] + [float("inf")] * n
+        pick = [0] * (n + 1)
+        for k in range(1, n + 1):
+            for b in S:
+                c = cost(b) + best[max(0, k - b)]
+                if c < best[k] - 1e-9:
+                    best[k], pick[k] = c, b
+        out, k = [], n
+        while k > 0:
+            out.append(pick[k])
+            k = max(0, k - pick[k])
+        out.sort(reverse=True)           # full batches first; only the last (smallest) one can be short
         return out
 
     # ------------------------------------------------------------------ region bookkeeping
@@ -289,6 +318,7 @@ class DeviceWindowTensor(InfiniteTensor):
         super().__init__((channels + 1, None, None), f, win, args=args, args_windows=args_windows,
                          tile_store=tile_store if tile_store is not None else DeviceTileStore(), tensor_id=tensor_id, batch_size=batch_size)
         self.channels, self.tile, self.stride_hw, self.engine = int(channels), int(tile), int(stride), engine
+        self.batch_cost_fixed = 8.0   # one U-Net launch sequence costs about as much as 8 windows of a full batch (1.7 ms vs 0.21 ms per window, base model)
         self.device = torch.device("cuda", engine.device_id)
         self.windows_computed = 0
 
@@ -301,9 +331,14 @@ class DeviceWindowTensor(InfiniteTensor):
             else:
                 out[c] = t
         self._prefetch_upstream(missing)
-        for chunk in (self._chunks(missing) if self.batch_size else [missing] if missing else []):
+        plan = self._plan_batches(len(missing)) if (self.batch_size and self.batch_sizes) else None
+        for ci, chunk in enumerate(self._chunks(missing) if self.batch_size else [missing] if missing else []):
             arg_lists = [[a[tuple(slice(l, h) for l, h in aw.bounds(c))] for c in chunk] for a, aw in zip(self.args, self.args_windows)]
-            res = self.f(list(chunk), *arg_lists)
+            pad = (plan[ci] - len(chunk)) if plan else 0
+            if pad > 0:   # padded plan: repeat the last window up to the allowed batch size (results of the repeats are dropped)
+                res = self.f(list(chunk) + [chunk[-1]] * pad, *[al + [al[-1]] * pad for al in arg_lists])[:len(chunk)]
+            else:
+                res = self.f(list(chunk), *arg_lists)
             assert res.is_cuda and tuple(res.shape) == (len(chunk), self.channels, self.tile, self.tile), (tuple(res.shape), res.device)
             self.windows_computed += len(chunk)
             for k, c in enumerate(chunk):

@@ -192,3 +192,18 @@ def test_pool_coarse_conditioning_host_matches_reference_golden(golden):
     assert pool_coarse_conditioning(x, 1) is x
     avg = pool_coarse_conditioning(x, 2)
     assert avg.shape == (6, 8, 8) and torch.allclose(avg[0], x[0].view(8, 2, 8, 2).mean(dim=(1, 3)))
+
+
+def test_batch_plan_with_cost_model_pads_the_tail():
+    """engine-backed tensors cut n missing windows into allowed batch sizes by cost (a call costs `batch_cost_fixed` windows + its size) and
+    may pad the last call: every plan covers n, only its smallest call can be short, and it is never worse than the greedy exact cut."""
+    t = InfiniteTensor(shape=(1, None, None), f=lambda c: None, output_window=TensorWindow((1, 4, 4), (1, 4, 4)), batch_size=(1, 2, 4, 8, 16, 32, 64))
+    cost = lambda plan: sum(8.0 + b for b in plan)
+    for n in range(1, 200):
+        t.batch_cost_fixed = None
+        greedy = t._plan_batches(n)
+        assert sum(greedy) == n
+        t.batch_cost_fixed = 8.0
+        plan = t._plan_batches(n)
+        assert sum(plan) >= n and sum(plan) - n < min(plan) and plan == sorted(plan, reverse=True) and cost(plan) <= cost(greedy) + 1e-9, (n, plan)
+    assert t._plan_batches(50) == [64] and t._plan_batches(30) == [32] and t._plan_batches(36) == [32, 4]
