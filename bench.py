@@ -178,6 +178,16 @@ def main():
         result["seam"] = {"bytes_total_per_step": seam.get("seam_bytes_total", 0), "bytes_sent_rank0_per_step": seam.get("seam_bytes_sent", 0),
                           "exchange_ms_per_step_rank0": round(seam.get("exchange_s", 0.0) / max(1, args.steps) * 1e3, 3),
                           "windows_rank0": seam.get("windows_this_rank"), "backend": "nccl (RCCL)" if world > 1 else "none (1 rank)"}
+        # the N = 1 DRIVER line is another workload (grid8, configs[2]); strong-scaling efficiency of THIS workload is value / (N x the committed
+        # one-rank measurement of the same workload), not value / (N x the grid8 number)
+        ref = os.path.join(ROOT, "profiles", "r02_bench_grid32_n1.json")
+        if world > 1 and os.path.exists(ref) and args.dtype == "bf16" and E == 20:
+            try:
+                one = json.loads(open(ref).read().strip().splitlines()[-1])
+                result["strong_scaling"] = {"one_rank_value_same_workload": one["value"], "source": os.path.relpath(ref, ROOT),
+                                            "speedup_vs_one_rank": round(value / one["value"], 3), "efficiency": round(value / one["value"] / world, 4)}
+            except Exception:
+                pass
 
     if rank == 0:
         peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "fp16") else PEAK_F32_TFLOPS
