@@ -904,7 +904,8 @@ static int run_unet(td_unet* u, Plan& pl, int step) {
         mark();
         hipError_t e = op.flavor == 3 ? launch_conv_pp(p, u->dt, op.bn, u->eng->n_cus, st)
                        : op.flavor == 2 ? launch_conv_glds(p, u->dt, op.narrow, op.bn, op.glds_variant, st) : launch_conv(p, u->dt, op.narrow, op.bn, 0, st);
-        mark(); if (prof) { ev_kind.push_back(0); char tag[96]; snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 3 ? "p" : op.flavor == 2 ? (op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit); ev_label.push_back(op.label + tag);
+        mark(); if (prof) { ev_kind.push_back(0); char tag[96]; double gf_ = 0.0; for (int si_ = 0; si_ < p.nseg; ++si_) gf_ += (double)p.seg[si_].C * p.seg[si_].taps; gf_ *= 2.0 * p.N * p.H * p.W * p.Cout * 1e-9;  /* algorithmic GFLOP of this launch */
+            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 3 ? "p" : op.flavor == 2 ? (op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_); ev_label.push_back(op.label + tag);
             double kk = 0; for (int s_ = 0; s_ < p.nseg; ++s_) kk += (double)p.seg[s_].C * p.seg[s_].taps;
             ev_flop.push_back(op.flavor >= 2 ? 2.0 * p.N * p.H * p.W * (double)p.Cout * kk : 0.0); }
         if (e != hipSuccess) return fail(TD_ERR_HIP, "conv launch " + op.label + ": " + hipGetErrorString(e));

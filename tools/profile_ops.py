@@ -28,5 +28,9 @@ conv_ms, conv_n, other_ms, other_n = eng.profile_read()
 tot = sum(r[1] for r in rows)
 print(f"batch {n} {dtype}: {tot / reps:.3f} ms kernel time per forward ({conv_n // reps} conv launches, {other_n // reps} other)")
 order = {}
-for r in sorted(rows, key=lambda r: -r[1])[:40]:
-    print(f"{r[1] / reps * 1e3:9.1f} us  {r[0]}")
+import re
+for r in sorted(rows, key=lambda r: -r[1])[:int(os.environ.get("TD_TOP", "40"))]:
+    us = r[1] / reps * 1e3
+    m = re.search(r" gf([0-9.]+)\]", r[0])
+    tf = f"{float(m.group(1)) / us * 1e3:7.1f} TF/s" if m and us > 0 else " " * 12   # GFLOP / us = PFLOP/s
+    print(f"{us:9.1f} us {tf}  {r[0]}")
