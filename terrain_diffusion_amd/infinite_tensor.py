@@ -212,6 +212,7 @@ class InfiniteTensor:
                     a, b, _ = s.indices(n)
             if n is not None and (a < 0 or b > n):
                 raise IndexError(f"index out of range on bounded dim {d}")
+            b = max(a, b)   # an inverted slice is empty, as in numpy / torch
             lo.append(a)
             hi.append(b)
         return lo, hi, squeeze
@@ -276,6 +277,11 @@ class InfiniteTensor:
 
     def __getitem__(self, idx):
         lo, hi, squeeze = self._normalize_slices(idx)
+        if any(h <= l for l, h in zip(lo, hi)):   # empty region: nothing to evaluate
+            region = torch.zeros([h - l for l, h in zip(lo, hi)], dtype=self.dtype)
+            for d in reversed(squeeze):
+                region = region.squeeze(d)
+            return region
         ctxs = sorted(self._windows_for(lo, hi))
         tiles = self._ensure(ctxs)
         region = torch.zeros([h - l for l, h in zip(lo, hi)], dtype=self.dtype)
@@ -350,6 +356,11 @@ class DeviceWindowTensor(InfiniteTensor):
     def __getitem__(self, idx):
         from .sampling import blend_windows
         lo, hi, squeeze = self._normalize_slices(idx)
+        if any(h <= l for l, h in zip(lo, hi)):   # empty region: nothing to evaluate
+            region = torch.zeros([h - l for l, h in zip(lo, hi)], dtype=torch.float32, device=self.device)
+            for d in reversed(squeeze):
+                region = region.squeeze(d)
+            return region
         if (lo[0], hi[0]) != (0, self.channels + 1):
             full = self[(slice(None), slice(lo[1], hi[1]), slice(lo[2], hi[2]))]
             sub = full[lo[0]:hi[0]]

@@ -207,3 +207,11 @@ def test_batch_plan_with_cost_model_pads_the_tail():
         plan = t._plan_batches(n)
         assert sum(plan) >= n and sum(plan) - n < min(plan) and plan == sorted(plan, reverse=True) and cost(plan) <= cost(greedy) + 1e-9, (n, plan)
     assert t._plan_batches(50) == [64] and t._plan_batches(30) == [32] and t._plan_batches(36) == [32, 4]
+
+
+def test_empty_and_inverted_slices_evaluate_nothing():
+    calls = []
+    t = InfiniteTensor(shape=(2, None, None), f=lambda c: (calls.append(c), torch.ones(2, 4, 4))[1], output_window=TensorWindow((2, 4, 4), (2, 2, 2)), tensor_id="e")
+    assert t[:, 0:0, 0:4].shape == (2, 0, 4) and t[:, 3:3, 5:5].shape == (2, 0, 0) and t[:, 4:2, 0:4].shape == (2, 0, 4)
+    assert not calls
+    assert t[:, -3:1, -2:0].shape == (2, 4, 2) and calls
