@@ -252,6 +252,11 @@ class WorldPipeline:
 
     def get(self, i1, j1, i2, j2, with_climate=True):
         """{'elev': (H, W) metres, 'climate': (5, H, W) or None} for the pixel box [i1,i2) x [j1,j2); device tensors."""
+        i1, j1, i2, j2 = int(i1), int(j1), int(i2), int(j2)
+        if i2 <= i1 or j2 <= j1:
+            raise ValueError(f"empty box [{i1},{i2}) x [{j1},{j2})")
+        if self.residual is None:
+            raise RuntimeError("bind() the pipeline first")
         elev = self._compute_elev(i1, j1, i2, j2, self.residual, scale=self.latent_compression)
         climate = self._compute_climate(i1, j1, i2, j2, elev, scale=self.latent_compression) if with_climate else None
         return {"elev": elev, "climate": climate}
