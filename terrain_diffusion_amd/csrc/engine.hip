@@ -523,7 +523,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
     // every option the plan builder reads is part of the cache key (a plan built under other options must never be reused)
     static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn", "pp",
                                                "pp_min_items_per_cu", "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
-                                               "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups"};
+                                               "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups", "glds_round_aware"};
     std::string key = std::to_string(N) + "_" + std::to_string(H) + "_" + std::to_string(W);
     for (const char* o : kPlanOptions) key += "_" + std::to_string((long long)u->eng->option(o, -7));
     if (lane) key += "_lane" + std::to_string(lane);   // a second, independent activation set of the same shape (concurrent half-batches)
@@ -627,6 +627,14 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
             // "batch_invariant": kernel flavour and K order do not depend on the batch size (no split-K, LDS-DMA flavour whenever it
             // applies), so a window's result is bit-identical whatever other windows share its batch / GPU.
             const bool inv = u->eng->option("batch_invariant", 0) != 0;
+            // round quantisation: when both cout tilings are legal, 96s win if they turn a partial last round of the CU slots into full rounds
+            // (768-cout layers at 16x16, batch 64: 768 workgroups of 128 couts = 1.5 rounds of 512 slots, 1024 of 96 couts = 2.0 rounds of
+            // workgroups that are 3/4 as long); the tile shape never changes the bits
+            if (bn2 == 128 && c96 && fbn == 0 && u->eng->option("glds_round_aware", 1) != 0) {
+                const int64_t slots_ = variant ? 512 : 256, w128 = mt2 * (cw.cout_pad / 128), w96 = mt2 * (cw.cout_pad / 96);
+                const double t128 = (double)((w128 + slots_ - 1) / slots_) * 128.0, t96 = (double)((w96 + slots_ - 1) / slots_) * 96.0 * 1.03;
+                if (t96 < 0.9 * t128) bn2 = 96;
+            }
             if (u->bf16 && bn2 && u->eng->option("glds", 1) && (inv || mt2 * (cw.cout_pad / bn2) >= u->eng->option("glds_min_wgs", 8))) {
                 op.flavor = 2; op.bn = bn2; op.glds_variant = variant;
                 const int TH2 = variant ? 8 : (op.narrow ? 8 : 16), NIMG2 = op.narrow ? (variant ? 2 : 4) : 1;
