@@ -81,10 +81,18 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     workload = args.workload or ("grid8" if world == 1 else "grid32")
+    # dry run of the N > 1 branch on a one-GPU box: TD_BENCH_ONE_GPU=1 puts every rank on cuda:0 and moves the seams through gloo / host
+    # memory (RCCL refuses two ranks on one device); the line then says so in seam.backend -- it is a plumbing check, not a measurement
+    one_gpu = os.environ.get("TD_BENCH_ONE_GPU", "0") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import terrain_diffusion_amd as td
     from terrain_diffusion_amd.engine import get_engine
@@ -156,7 +164,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert bool(torch.isfinite(out).all())
@@ -181,7 +189,7 @@ def main():
     if strong:
         result["seam"] = {"bytes_total_per_step": seam.get("seam_bytes_total", 0), "bytes_sent_rank0_per_step": seam.get("seam_bytes_sent", 0),
                           "exchange_ms_per_step_rank0": round(seam.get("exchange_s", 0.0) / max(1, args.steps) * 1e3, 3),
-                          "windows_rank0": seam.get("windows_this_rank"), "backend": "nccl (RCCL)" if world > 1 else "none (1 rank)"}
+                          "windows_rank0": seam.get("windows_this_rank"), "backend": ("gloo through host memory, all ranks on ONE GPU (dry run)" if one_gpu else "nccl (RCCL)") if world > 1 else "none (1 rank)"}
         # the N = 1 DRIVER line is another workload (grid8, configs[2]); strong-scaling efficiency of THIS workload is value / (N x the committed
         # one-rank measurement of the same workload), not value / (N x the grid8 number)
         ref = os.path.join(ROOT, "profiles", "r02_bench_grid32_n1.json")

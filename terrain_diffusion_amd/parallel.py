@@ -91,12 +91,16 @@ def exchange_windows(plan: ShardPlan, rank, my_tiles, group=None):
     local_index = {w: i for i, w in enumerate(plan.windows[rank])}
     have = {w: my_tiles[local_index[w]] for w in plan.needed[rank] if plan.owner[w] == rank}
     ops, recv_bufs = [], {}
+    # gloo moves host memory only: device tiles are staged through the host (CPU tests, and the one-GPU dry run of bench.py's N > 1 branch);
+    # RCCL ("nccl") sends the device buffers themselves over xGMI
+    host_stage = my_tiles.is_cuda and dist.get_backend(group) == "gloo"
+    xdev = torch.device("cpu") if host_stage else my_tiles.device
     for (s, d), wins in sorted(plan.sends.items()):
         if s == rank:
-            buf = torch.stack([my_tiles[local_index[w]] for w in wins]).contiguous()
+            buf = torch.stack([my_tiles[local_index[w]] for w in wins]).contiguous().to(xdev)
             ops.append(dist.P2POp(dist.isend, buf, d, group))
         elif d == rank:
-            buf = torch.empty((len(wins),) + tuple(my_tiles.shape[1:]), dtype=my_tiles.dtype, device=my_tiles.device)
+            buf = torch.empty((len(wins),) + tuple(my_tiles.shape[1:]), dtype=my_tiles.dtype, device=xdev)
             recv_bufs[s] = (buf, wins)
             ops.append(dist.P2POp(dist.irecv, buf, s, group))
     if ops:
@@ -106,6 +110,8 @@ def exchange_windows(plan: ShardPlan, rank, my_tiles, group=None):
             # RCCL's wait() only orders the transfer before later work on torch's CURRENT stream; the engine blends on its own stream
             torch.cuda.current_stream(my_tiles.device).synchronize()
     for s, (buf, wins) in recv_bufs.items():
+        if host_stage:
+            buf = buf.to(my_tiles.device)
         for i, w in enumerate(wins):
             have[w] = buf[i]
     return have

@@ -301,3 +301,23 @@ def test_decoder_window_at_real_size(td, dtype, tol):
     print(f"decoder 512x512 window {dtype}: rel-RMS vs oracle {err:.3e}")
     assert err < tol
     md.close()
+
+
+def test_bench_multi_rank_branch_dry_run_on_one_gpu():
+    """bench.py --gpus 2 end to end on ONE GPU (TD_BENCH_ONE_GPU=1: both ranks on cuda:0, seams through gloo / host memory -- RCCL refuses two
+    ranks on one device): self-launch through torch.distributed.run, 2-D block mesh, seam exchange, per-rank blend, max-over-ranks timing and the
+    N > 1 JSON line (strong scaling, seam object).  A plumbing check of the branch the 8-GPU driver run takes, not a measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TD_BENCH_ONE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--edm-steps", "2"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["decoded_mp_per_step"] == pytest.approx(71.368704)
+    assert d["seam"]["bytes_total_per_step"] == 32 * 5 * 64 * 64 * 4 and d["seam"]["windows_rank0"] == 512 and "dry run" in d["seam"]["backend"]
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
