@@ -375,6 +375,10 @@ def test_sharded_sampling_simulated_ranks(td, orc):
         cond = tiling.synthetic_cond_grid(len(tiling.tile_starts(H, S, S // 2)), len(tiling.tile_starts(W, S, S // 2)))
         kw = dict(cond_means=torch.zeros(7), cond_stds=torch.ones(7), noise_level=torch.tensor(0.0), histogram_raw=torch.zeros(1, 5))
         ref = td.sample_base_diffusion(m, sch, (1, 5, H, W), cond, steps=steps, tile_size=S, noise_seed=7, **kw)
+        # the sharded runs also use the two-lane sampler (engine option dual_stream: half-batches on two HIP streams, what bench.py switches on
+        # for the strong-scaling workload): in batch-invariant mode the lane split must not change a bit either
+        eng.set_option("dual_stream", 1)
+        eng.set_option("dual_stream_min_batch", 2)
         for world in (2, 4):
             plan = ShardPlan(H, W, S, world)
             fns = engine_fns(m, sch, plan, cond, steps=steps, channels=5, noise_seed=7, noise_origin=(0, 0), max_batch=64, **kw)
@@ -391,6 +395,8 @@ def test_sharded_sampling_simulated_ranks(td, orc):
         m.close()
     finally:
         eng.set_option("batch_invariant", 0)
+        eng.set_option("dual_stream", 0)
+        eng.set_option("dual_stream_min_batch", 32)
 
 
 def test_infinite_latent_stage_vs_oracle(td, orc):
