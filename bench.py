@@ -224,7 +224,8 @@ def main():
                          "other_unet_kernel_ms_per_step": round(other_ms, 3)})
             if g_n > 0:   # dominant kernel family: the LDS-DMA implicit-GEMM conv (terrain_diffusion_amd/csrc/conv_glds.hip / conv_pp.hip)
                 ach = g_flop / (g_ms * 1e-3) / 1e12
-                lanes = 2 if ("dual_stream=1" in args.engine_opts and min(tiles_per_step, 64) >= 32) else 1
+                dual_on = "dual_stream=1" in args.engine_opts or (strong and "dual_stream=0" not in args.engine_opts)
+                lanes = 2 if (dual_on and min(tiles_per_step, 64) >= 32) else 1
                 share = g_ms / (conv_ms + other_ms)
                 iso = {"achieved": round(ach, 2), "frac": round(ach / peak, 4), "avg_launch_us": round(g_ms / g_n * 1e3, 3), "kernel_ms_per_step": round(g_ms, 3)}
                 roof.update({"launches_per_step": g_n, "flop_per_launch": round(g_flop / g_n), "share_of_unet_kernel_time": round(share, 4), "lanes": lanes})
