@@ -70,6 +70,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
 #ifndef TD_NO_XCD_REMAP
     if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
 #endif
+    // the host alternates `reverse` from layer to layer: a layer then reads first what its producer wrote last, which is still in the 256 MB
+    // Infinity Cache (chained A/B on the 192-channel 64x64 layers: -7...-11 % time; profiles/r03_conv_walk_order_and_stagger.txt)
+    if (p.reverse) bid = (int)gridDim.x - 1 - bid;
     const int ntile = bid % p.n_ntiles; bid /= p.n_ntiles;
     const int mtiles = p.tiles_x * p.tiles_y * p.img_groups;
     const int mtile = bid % mtiles;
@@ -458,6 +461,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
         }
     }
 #ifdef TD_TRACE
+    TD_T(tr_eissue);  // epilogue instructions issued; the stores are still in flight
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TD_T(tr_end);
     if (lane == 0) {
@@ -465,16 +469,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
         tb[0] = tr_pro - tr_start; tb[1] = tr_loop - tr_pro; tb[2] = tr_end - tr_loop; tb[3] = tr_wait; tb[4] = tr_stage; tb[5] = tr_start; tb[6] = tr_end;
         tb[8] = tr_rt0; tb[9] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8) | __builtin_amdgcn_s_getreg((3 << 11) | 20);
         tb[10] = __builtin_amdgcn_s_memrealtime();
-        tb[7] = tb[10] - tr_rt0;  // 100 MHz constant clock: shader clock = 100 MHz * (tb[6]-tb[5]) / tb[7]
+        tb[7] = tb[10] - tr_rt0; tb[11] = tr_end - tr_eissue;  // 100 MHz constant clock: shader clock = 100 MHz * (tb[6]-tb[5]) / tb[7]
     }
 #endif
 }
+
+int g_bench_extra_lds = 0;  // tools/conv_bench.hip only: extra dynamic LDS per workgroup, to force one workgroup per CU in occupancy experiments
 
 template <typename T, int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N>
 static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
     constexpr int NPATCH = NIMG * (TH + 2) * (TW == 8 ? 12 : TW + 2);
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
-    const size_t lds = (size_t)NPATCH * 144 + 3 * (size_t)(((BN * 128 + NTHR * 16 - 1) / (NTHR * 16)) * NTHR * 16) + NPATCH * 4;
+    const size_t lds = (size_t)NPATCH * 144 + 3 * (size_t)(((BN * 128 + NTHR * 16 - 1) / (NTHR * 16)) * NTHR * 16) + NPATCH * 4 + (size_t)g_bench_extra_lds;
     bool seen1 = false;  // the kernel's compile-time ring slots need every 3x3 segment to start on a multiple of 3 K-steps
     for (int s = 0; s < p.nseg; ++s) { if (p.seg[s].taps == 9 && seen1) return hipErrorInvalidValue; if (p.seg[s].taps != 9) seen1 = true; }
     const int grid = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * p.ksplit;
@@ -482,7 +488,7 @@ static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
     // per (instantiation, device): hipFuncSetAttribute applies to the CURRENT device's copy of the kernel only
     static bool attr_set[64] = {};
     int dev_ = 0; (void)hipGetDevice(&dev_);
-    if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_]) {
+    if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_] || g_bench_extra_lds) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;

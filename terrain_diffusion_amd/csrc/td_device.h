@@ -49,6 +49,8 @@ struct ConvParams {
     void* out2;           // optional second output, same layout as out: mp_silu(out2_scale * out) -- the consumer's activation, done once here
     float out2_scale;
     const void* zeros;    // >= 16 zero bytes in device memory: source of the halo outside the image for LDS-DMA patch staging (conv_pp.hip)
+    int reverse;          // scheduling hint (speed only, never changes a bit): 1 = logical workgroup ids are walked backwards (the host alternates it
+                          // from layer to layer: the producer's last-written, still cached rows are read first)
 };
 
 struct SchedCoef {        // one DPM-Solver++ step, fp32 scalars computed on the host

@@ -11,12 +11,14 @@
 #include "conv_igemm.hip"
 #include "conv_glds.hip"
 #include "conv_pp.hip"
+#include "experiments/conv_ps.hip"
 using namespace td;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 int main(int argc, char** argv) {
     int N = argc > 1 ? atoi(argv[1]) : 64, H = argc > 2 ? atoi(argv[2]) : 64, W = argc > 3 ? atoi(argv[3]) : 64;
     int Cin = argc > 4 ? atoi(argv[4]) : 192, Cout = argc > 5 ? atoi(argv[5]) : 192, taps = argc > 6 ? atoi(argv[6]) : 9;
     int xform = argc > 7 ? atoi(argv[7]) : 0, bn = argc > 8 ? atoi(argv[8]) : 64, ksplit = argc > 9 ? atoi(argv[9]) : 1, flavor = argc > 10 ? atoi(argv[10]) : 0, epi = argc > 11 ? atoi(argv[11]) : 0;
+    const int stagger = argc > 12 ? atoi(argv[12]) : 0, chain = argc > 13 ? atoi(argv[13]) : 0, want_out2 = argc > 14 ? atoi(argv[14]) : 0;  // chain: 1 = x->y->x same walk order, 2 = second layer walks backwards
     const int chunk = 64;
     size_t M = (size_t)N * H * W;
     int kgroups = Cin / chunk, ksteps = kgroups * taps;
@@ -35,25 +37,53 @@ int main(int argc, char** argv) {
     ConvParams p; memset(&p, 0, sizeof p);
     p.nseg = 1; p.seg[0].src = x; p.seg[0].C = Cin; p.seg[0].cstride = Cin; p.seg[0].Hs = H; p.seg[0].Ws = W; p.seg[0].taps = taps; p.seg[0].xform = xform; p.seg[0].scale = 1.f;
     p.wpack = w; p.N = N; p.H = H; p.W = W; p.Cout = Cout; p.CoutPad = Cout; p.kgroups = kgroups; p.ksplit = ksplit; p.partial = partial;
-    bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4) ? 4 : 2) : 1; int TH = ((flavor == 2 || flavor == 4 || flavor == 5) && !narrow) ? 16 : 8;
+    bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4 || flavor == 6) ? 4 : 2) : 1; int TH = ((flavor == 2 || flavor == 4 || flavor == 5 || flavor == 6) && !narrow) ? 16 : 8;
     p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH; p.img_groups = (N + NIMG - 1) / NIMG; p.n_ntiles = Cout / bn;
     p.epi = epi; p.out = out; p.out_cstride = Cout;
     { void* z; CK(hipMalloc(&z, 4096)); CK(hipMemset(z, 0, 4096)); p.zeros = z; }
     if (epi == EPI_EMB_SILU) { float* cv; CK(hipMalloc(&cv, (size_t)N * Cout * 4)); std::vector<float> hc((size_t)N * Cout, 1.01f); CK(hipMemcpy(cv, hc.data(), hc.size() * 4, hipMemcpyHostToDevice)); p.cvec = cv; p.cvec_stride = Cout; }
     if (epi == EPI_RESIDUAL) { void* r; float* ssq; CK(hipMalloc(&r, M * Cout * 2)); CK(hipMemcpy(r, hx.data(), std::min(hx.size(), M * Cout) * 2, hipMemcpyHostToDevice)); CK(hipMalloc(&ssq, M * (Cout / 32 + 8) * 4)); CK(hipMemset(ssq, 0, M * (Cout / 32 + 8) * 4));
         p.res = r; p.res_cstride = Cout; p.res_Hs = H; p.res_Ws = W; p.res_scale = 0.9f; p.clip = 256.f; p.out_sumsq = ssq; }
+    (void)stagger;  // round-3 stagger experiments are recorded in profiles/r03_conv_walk_order_and_stagger.txt; the hook is gone from the kernel
+    if (want_out2) { void* o2; CK(hipMalloc(&o2, M * Cout * 2)); p.out2 = o2; p.out2_scale = 1.f; }
+    ConvParams p2 = p;
+    if (chain) { if (Cin != Cout) { printf("chain needs Cin == Cout\n"); return 1; } p2.seg[0].src = out; p2.out = x; p2.reverse = chain == 2 ? 1 : 0; }
+    if (getenv("TD_EXTRA_LDS")) g_bench_extra_lds = atoi(getenv("TD_EXTRA_LDS"));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) CK((flavor == 5 ? launch_conv_pp(p, 1, bn, 256, st) : flavor >= 2 ? launch_conv_glds(p, 1, narrow, bn, flavor - 2, st) : launch_conv(p, 1, narrow, bn, flavor, st)));
+    auto L = [&](const ConvParams& q) { return flavor >= 6 ? launch_conv_ps(q, 1, narrow, bn, flavor - 6, 256, st) : flavor == 5 ? launch_conv_pp(q, 1, bn, 256, st) : flavor >= 2 ? launch_conv_glds(q, 1, narrow, bn, flavor - 2, st) : launch_conv(q, 1, narrow, bn, flavor, st); };
+    for (int i = 0; i < 4; ++i) CK(L((chain && (i & 1)) ? p2 : p));
     CK(hipStreamSynchronize(st));
     const int reps = 20;
     CK(hipEventRecord(e0, st));
-    for (int i = 0; i < reps; ++i) CK((flavor == 5 ? launch_conv_pp(p, 1, bn, 256, st) : flavor >= 2 ? launch_conv_glds(p, 1, narrow, bn, flavor - 2, st) : launch_conv(p, 1, narrow, bn, flavor, st)));
+    for (int i = 0; i < reps; ++i) CK(L((chain && (i & 1)) ? p2 : p));
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     double flop = 2.0 * M * Cout * Cin * taps;
-    printf("N%d %dx%d Cin%d Cout%d taps%d xform%d bn%d ks%d fl%d epi%d : %.1f us  %.1f TFLOP/s (%.1f%% of 2500)  wgs=%d\n", N, H, W, Cin, Cout, taps, xform, bn, ksplit, flavor, epi, ms * 1e3,
+    printf("N%d %dx%d Cin%d Cout%d taps%d xform%d bn%d ks%d fl%d epi%d stg%d ch%d : %.1f us  %.1f TFLOP/s (%.1f%% of 2500)  wgs=%d\n", N, H, W, Cin, Cout, taps, xform, bn, ksplit, flavor, epi, stagger, chain, ms * 1e3,
            flop / ms / 1e9, flop / ms / 1e9 / 25.0, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * ksplit);
+#ifndef TD_TRACE
+    if (flavor >= 6) {  // bit-exactness of the persistent-stream flavour against conv_glds with the same tile shape
+        std::vector<uint16_t> o5(M * Cout), o2(M * Cout), q5, q2;
+        std::vector<float> s5, s2;
+        const ConvParams& pp_ = p;
+        CK(hipMemset(pp_.out, 0, M * Cout * 2)); if (pp_.out2) CK(hipMemset(pp_.out2, 0, M * Cout * 2)); if (pp_.out_sumsq) CK(hipMemset(pp_.out_sumsq, 0, M * (Cout / 32) * 4));
+        CK(launch_conv_ps(pp_, 1, narrow, bn, flavor - 6, 256, st)); CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(o5.data(), pp_.out, o5.size() * 2, hipMemcpyDeviceToHost));
+        if (pp_.out2) { q5.resize(M * Cout); CK(hipMemcpy(q5.data(), pp_.out2, q5.size() * 2, hipMemcpyDeviceToHost)); }
+        if (pp_.out_sumsq) { s5.resize(M * (Cout / 32)); CK(hipMemcpy(s5.data(), pp_.out_sumsq, s5.size() * 4, hipMemcpyDeviceToHost)); }
+        CK(hipMemset(pp_.out, 0, M * Cout * 2)); if (pp_.out2) CK(hipMemset(pp_.out2, 0, M * Cout * 2)); if (pp_.out_sumsq) CK(hipMemset(pp_.out_sumsq, 0, M * (Cout / 32) * 4));
+        CK(launch_conv_glds(pp_, 1, narrow, bn, flavor - 6, st)); CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(o2.data(), pp_.out, o2.size() * 2, hipMemcpyDeviceToHost));
+        if (pp_.out2) { q2.resize(M * Cout); CK(hipMemcpy(q2.data(), pp_.out2, q2.size() * 2, hipMemcpyDeviceToHost)); }
+        if (pp_.out_sumsq) { s2.resize(M * (Cout / 32)); CK(hipMemcpy(s2.data(), pp_.out_sumsq, s2.size() * 4, hipMemcpyDeviceToHost)); }
+        size_t bad = 0, first = 0; for (size_t i = 0; i < o5.size(); ++i) if (o5[i] != o2[i]) { if (!bad) first = i; ++bad; }
+        size_t badq = 0; for (size_t i = 0; i < q5.size(); ++i) if (q5[i] != q2[i]) ++badq;
+        size_t bads = 0; for (size_t i = 0; i < s5.size(); ++i) if (memcmp(&s5[i], &s2[i], 4)) ++bads;
+        size_t nz = 0; for (auto v : o2) nz += (v & 0x7fff) != 0;
+        printf("  check vs conv_glds: %zu / %zu outputs differ (first at %zu: pixel %zu cout %zu), out2 diffs %zu, sumsq diffs %zu, nonzero outputs %zu\n", bad, o5.size(), first, first / Cout, first % Cout, badq, bads, nz);
+    }
+#endif
     if (flavor == 5) {  // bit-exactness of the persistent ping-pong flavour against the LDS-DMA flavour (same K order, same MFMA)
         std::vector<uint16_t> o5(M * Cout), o2(M * Cout);
         CK(hipMemset(out, 0, M * Cout * 2));
@@ -85,7 +115,8 @@ int main(int argc, char** argv) {
 #endif
 #ifdef TD_TRACE
     {
-        const int wgs = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, nw = flavor == 4 ? 12 : (flavor == 3 ? 4 : 8), TS = 16;  // waves per workgroup of the variant, u64 per wave record
+        int wgs = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups; const int nw = flavor == 4 ? 12 : ((flavor == 3 || flavor == 7) ? 4 : 8), TS = 16;
+        if (flavor >= 6) { int g = flavor == 7 ? 512 : 256; while (g > 8 && g - 8 >= wgs) g -= 8; wgs = g; }  // persistent grid  // waves per workgroup of the variant, u64 per wave record
         std::vector<unsigned long long> tb((size_t)wgs * nw * TS);
         CK(hipMemcpy(tb.data(), partial, tb.size() * 8, hipMemcpyDeviceToHost));
         double s[5] = {0, 0, 0, 0, 0}; unsigned long long t0 = ~0ull, t1 = 0;
@@ -105,6 +136,9 @@ int main(int argc, char** argv) {
         printf("  trace (s_memtime ticks, mean per wave): prologue %.0f  loop %.0f (of which tap-entry wait %.0f, restage %.0f, body %.0f)  epilogue %.0f  | WG total %.0f | kernel span %.0f ticks = %.2f ticks/us\n",
                s[0], s[1], s[3], s[4], s[1] - s[3] - s[4], s[2], s[0] + s[1] + s[2], (double)(t1 - t0), (double)(t1 - t0) / (ms * 1e3));
         printf("  taps per WG: %d  -> body %.0f ticks/tap, wait %.0f ticks/tap\n", ksteps, (s[1] - s[3] - s[4]) / ksteps, s[3] / ksteps);
+        if (flavor >= 6) { double it = 0, pro = 0, adv = 0; for (int i = 0; i < wgs * nw; ++i) { it += (double)tb[(size_t)i * TS + 11]; pro += (double)tb[(size_t)i * TS + 12]; adv += (double)tb[(size_t)i * TS + 13]; }
+            printf("  persistent: %.2f items per wave; first prologue %.0f ticks, cursor advance %.0f ticks in total; per item: taps+restage %.0f, epilogue %.0f, advance %.0f\n", it / (wgs * nw), pro / (wgs * nw), adv / (wgs * nw), s[1] / (it / (wgs * nw)), s[2] / (it / (wgs * nw)), adv / it); }
+        { double dr = 0; for (int i = 0; i < wgs * nw; ++i) dr += (double)tb[(size_t)i * TS + 11]; printf("  of the epilogue: %.0f ticks waiting for the stores to drain after the last one was issued\n", dr / ((double)wgs * nw)); }
     }
 #endif
     return 0;
