@@ -1184,7 +1184,7 @@ static int sample_edm_lane(td_unet* u, td_unet* guide, float gscale, int n, int 
                            const float* cond, const float* cond_img, int cimg, float* x, int lane, std::vector<Buf>& hold) {
     if (guide) {
         if (!guide->finalized) return fail(TD_ERR_STATE, "finalize the guide model first");
-        if (guide->eng != u->eng || guide->bf16 != u->bf16) return fail(TD_ERR_ARG, "guide model must live on the same engine and use the same dtype");
+        if (guide->eng != u->eng || guide->dt != u->dt) return fail(TD_ERR_ARG, "guide model must live on the same engine and use the same dtype");
         if (guide->cfg.in_channels != u->cfg.in_channels || guide->cfg.out_channels != u->cfg.out_channels || guide->cond_row_len != u->cond_row_len)
             return fail(TD_ERR_ARG, "guide model must take the same inputs as the main model");
     }

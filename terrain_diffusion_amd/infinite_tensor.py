@@ -122,6 +122,28 @@ class HDF5TileStore(MemoryTileStore):
         while len(self._d) > self.cache_size_tiles:
             self._d.popitem(last=False)
 
+    # ---- WORLD_PIPELINE_PARAMS attribute of the world file (world_pipeline.py:625-664: json with sorted keys)
+    ATTR_KEY = "WORLD_PIPELINE_PARAMS"
+
+    @property
+    def params(self):
+        import json
+        return json.loads(self._h5.attrs[self.ATTR_KEY]) if self.ATTR_KEY in self._h5.attrs else None
+
+    @params.setter
+    def params(self, value):
+        import json
+        self._h5.attrs[self.ATTR_KEY] = json.dumps(value, sort_keys=True)
+        self._h5.flush()
+
+    def clear(self, tensor_id=None):
+        """Drops the in-memory windows AND the datasets on disk (empty_cache() must not be undone by the next get())."""
+        super().clear(tensor_id)
+        for g in ([str(tensor_id)] if tensor_id is not None else list(self._h5.keys())):
+            if g in self._h5:
+                del self._h5[g]
+        self._h5.flush()
+
     def close(self):
         self._h5.close()
         MemoryTileStore.clear(self)
@@ -364,7 +386,9 @@ class DeviceWindowTensor(InfiniteTensor):
         if (lo[0], hi[0]) != (0, self.channels + 1):
             full = self[(slice(None), slice(lo[1], hi[1]), slice(lo[2], hi[2]))]
             sub = full[lo[0]:hi[0]]
-            return sub.squeeze(0) if 0 in squeeze else sub
+            for d in reversed(squeeze):   # integer indices on ANY dimension drop it, as in InfiniteTensor.__getitem__ and the full-channel path
+                sub = sub.squeeze(d)
+            return sub
         ctxs = sorted(self._windows_for(lo, hi))
         tiles = self._ensure(ctxs)
         rows = sorted({c[1] for c in ctxs})

@@ -73,8 +73,14 @@ class SyntheticMapFactory:
         return out
 
     def sample_raw(self, i1, j1, i2, j2):
-        """(5, i2-i1, j2-j1) transferred noise before `finalize`  (synthetic_map.py:254-260: x runs over [i1,i2), y over [j1,j2))."""
-        return torch.stack([self._channel(ch, i1, j1, i2 - i1, j2 - j1) for ch in range(5)])
+        """(5, i2-i1, j2-j1) transferred noise before `finalize`, in the REFERENCE's orientation (synthetic_map.py:207-218):
+        x = arange(i1, i2), y = arange(j1, j2), np.meshgrid(x, y) in 'xy' order, values flattened row-major and reshaped to (i2-i1, j2-j1).
+        For a square request that is out[r, c] = noise(x = i1 + c, y = j1 + r) -- the transpose of the natural order, which WorldPipeline
+        undoes with its (i, j) -> (j, i) argument swap (world_pipeline.py:901), so that world cell (I, J) always sees noise(J, I) whatever
+        window asks for it.  For a non-square request the reference's reshape scrambles rows; reproduced as written (the pipeline only asks
+        for square windows).  `_channel` is the kernel's natural order K[r][c] = noise(i1 + r, j1 + c): out = K^T flattened and reshaped."""
+        n, m = i2 - i1, j2 - j1
+        return torch.stack([self._channel(ch, i1, j1, n, m).t().contiguous().reshape(n, m) for ch in range(5)])
 
     def finalize(self, raw):
         """synthetic_map.py:232-252, same arithmetic on device tensors."""

@@ -51,9 +51,13 @@ class FileTileStore(MemoryTileStore):
     def __init__(self, path, mode="a", compression=None, compression_opts=None, cache_size_tiles=100):
         super().__init__(cache_size_bytes=None)
         self.path, self.cache_size_tiles = path, cache_size_tiles
-        if mode == "w" and os.path.isdir(path):
+        if os.path.exists(path) and not os.path.isdir(path):
+            raise ValueError(f"{path!r} is a regular file: FileTileStore keeps its records in a DIRECTORY of .npy files (an HDF5 world file of the "
+                             "reference needs h5py, which this environment does not have)")
+        if mode == "w" and os.path.isdir(path):   # truncate: only this store's own records, never a user's other files
             for f in os.listdir(path):
-                os.remove(os.path.join(path, f))
+                if f.endswith(".npy") or f == "params.json":
+                    os.remove(os.path.join(path, f))
         os.makedirs(path, exist_ok=True)
 
     @staticmethod

@@ -123,20 +123,44 @@ class WorldPipeline:
     def _params(self):
         return {"seed": self.seed, "kwargs": self.kwargs}
 
-    def bind(self, hdf5_file=None, mode="a", compression="gzip", compression_opts=4):
+    def bind(self, hdf5_file=None, mode="a", compression="gzip", compression_opts=4, on_param_mismatch="stored"):
+        """world_pipeline.py:587-621.  hdf5_file='TEMP' makes a temporary world that close() removes.  When the world file already records other
+        parameters than this pipeline's (seed / kwargs), the reference asks on the console whether to overwrite them; a library cannot, so
+        `on_param_mismatch` decides: 'stored' (the reference's default answer: keep the stored world and adopt ITS seed and kwargs, with a
+        warning that lists the differences), 'overwrite' (the reference's 'y') or 'error'."""
+        if on_param_mismatch not in ("stored", "overwrite", "error"):
+            raise ValueError("on_param_mismatch must be 'stored', 'overwrite' or 'error'")
         if self.caching_strategy == "direct":
             self._init_tile_store(None, None)
         else:
             if hdf5_file is None:
                 raise ValueError("hdf5_file is required when caching_strategy='indirect'")
+            self._is_temp_file = str(hdf5_file).upper() == "TEMP"
+            if self._is_temp_file:
+                import tempfile
+                hdf5_file = tempfile.mkdtemp(prefix="terrain_")   # FileTileStore keeps a directory; with h5py the file lives inside it
+                self._temp_dir = hdf5_file
+                try:
+                    import h5py  # noqa: F401
+                    hdf5_file = os.path.join(hdf5_file, "world.h5")
+                except ImportError:
+                    pass
             self._store_path = hdf5_file
             self._init_tile_store(hdf5_file, mode, compression, compression_opts)
+            current = json.loads(json.dumps(self._params()))
             stored = getattr(self.tile_store, "params", None)
             if stored is None:
-                self.tile_store.params = json.loads(json.dumps(self._params()))
-            elif stored != json.loads(json.dumps(self._params())):
-                # the reference prompts on the console (world_pipeline.py:641-664); a library cannot: keep the stored world, as its default answer does
-                self.seed, self.kwargs = stored["seed"], stored["kwargs"]
+                self.tile_store.params = current
+            elif stored != current:
+                diffs = {k: (stored.get(k), current[k]) for k in current if stored.get(k) != current[k]}
+                if on_param_mismatch == "error":
+                    raise ValueError(f"world file {hdf5_file!r} was made with other parameters (stored, current): {diffs}")
+                if on_param_mismatch == "overwrite":
+                    self.tile_store.params = current
+                else:
+                    import warnings
+                    warnings.warn(f"world file {hdf5_file!r} was made with other parameters; keeping the STORED world (stored, current): {diffs}")
+                    self.seed, self.kwargs = stored["seed"], stored["kwargs"]
         self._init_conditioning()
         self._build_hierarchy()
         return self
@@ -271,6 +295,10 @@ class WorldPipeline:
     def close(self):
         if self.tile_store is not None and hasattr(self.tile_store, "close"):
             self.tile_store.close()
+        if getattr(self, "_is_temp_file", False) and getattr(self, "_temp_dir", None):   # world_pipeline.py:711-713
+            import shutil
+            shutil.rmtree(self._temp_dir, ignore_errors=True)
+            self._temp_dir = None
 
     def __enter__(self):
         return self

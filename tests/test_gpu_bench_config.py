@@ -178,6 +178,59 @@ def test_config2_grid8_end_to_end(td, base):
     assert rel_rms(y[0, :, :32, :32].cpu().numpy(), (ref[0][:, :32, :32] / 0.5).numpy()) < 2e-2
 
 
+def test_config3_grid32_full_size_one_gpu(td, base):
+    """BASELINE configs[3] at FULL size on one GPU: 32x32 windows of 64x64 (stride 32) on the 1056x1056 latent canvas,
+    all 20 DPM-Solver++ steps, bf16, batch-invariant mode (what the sharded run uses), 16 batches of 64 windows.
+      * four windows -- corner, top edge, interior, last row / last column -- against the oracle BEFORE the blend, as test_config2 does;
+      * the one-rank canvas against the canvas assembled from TWO simulated ranks (ShardPlan's 2-D block mesh, the seam windows handed over in
+        memory, every rank blending its own region): bit for bit.
+    The multi-rank dry run of bench.py only ran 2 of the 20 steps and checked properties; this is the full-size comparison it lacked."""
+    from oracle import rng, tiling
+    from terrain_diffusion_amd.engine import get_engine
+    from terrain_diffusion_amd.parallel import ShardPlan, engine_fns, blend_region
+    m, om = base
+    eng = get_engine("cuda")
+    eng.set_option("batch_invariant", 1)
+    try:
+        sch = td.EDMDPMSolverMultistepScheduler(sigma_min=0.002, sigma_max=80.0, sigma_data=0.5)
+        H = W = 1056
+        starts = tiling.tile_starts(H, 64, 32)
+        assert len(starts) == 32
+        cond = tiling.synthetic_cond_grid(32, 32)
+        seed = 42 + 5819
+        kw = dict(cond_means=torch.zeros(7), cond_stds=torch.ones(7), noise_level=torch.tensor(0.0), histogram_raw=torch.zeros(1, 5))
+        y, win = td.sample_base_diffusion(m, sch, (1, 5, H, W), cond, steps=20, tile_size=64, noise_seed=seed, max_batch=64, return_windows=True, **kw)
+        assert len(win) == 1024 and tuple(y.shape) == (1, 5, H, W) and torch.isfinite(y).all()
+        pick = [(0, 0), (0, 17), (16, 13), (31, 31)]
+        noise = torch.stack([torch.from_numpy(rng.gaussian_noise_patch(seed, starts[i], starts[j], 64, 64, channels=5, tile_h=64, tile_w=64)) for i, j in pick])
+        c58 = torch.cat([tiling.process_cond_img(cond[..., i:i + 4, j:j + 4], torch.zeros(1, 5), torch.zeros(7), torch.ones(7), 0.0) for i, j in pick])
+        ref = _oracle_windows(om, noise, c58, 20)
+        errs = [rel_rms(win[t].cpu().numpy(), ref[k].numpy()) for k, t in enumerate(pick)]
+        print("configs[3] windows (0,0) (0,17) (16,13) (31,31), bf16 x 20 steps, batch-invariant, vs oracle:", ["%.3e" % e for e in errs])
+        assert max(errs) < 2e-2, errs
+        # the canvas corner only the first window reaches, end to end against the oracle
+        assert rel_rms(y[0, :, :32, :32].cpu().numpy(), (ref[0][:, :32, :32] / 0.5).numpy()) < 2e-2
+        del win
+        # two simulated ranks: same plan / seam lists / regional blend as the RCCL path (parallel.py), exchange done in memory
+        plan = ShardPlan(H, W, 64, 2)
+        fns = engine_fns(m, sch, plan, cond, steps=20, channels=5, noise_seed=seed, noise_origin=(0, 0), max_batch=64, **kw)
+        tiles = [fns[0](plan.windows[r]) for r in range(2)]
+        full = torch.empty((5, H, W), device="cuda")
+        seam = 0
+        for r in range(2):
+            have = {}
+            for w_ in plan.needed[r]:
+                o = plan.owner[w_]
+                have[w_] = tiles[o][plan.windows[o].index(w_)]
+                seam += o != r
+            y0, y1, x0, x1 = plan.regions[r]
+            full[:, y0:y1, x0:x1] = blend_region(plan, r, have, fns[1], fns[2], 5, 1.0 / 0.5)
+        assert seam == 32, seam                      # one column (or row) of 32 windows reaches into the neighbour's region
+        assert torch.equal(full[None], y), "two-rank canvas differs from the one-rank canvas"
+    finally:
+        eng.set_option("batch_invariant", 0)
+
+
 def test_fp16_tile_variants_bit_identical_and_close_to_bf16(td):
     """fp16 storage runs through the same conv flavours (v_mfma_f32_32x32x16_f16): the tile-shape identity holds there too, and the result sits
     closer to the fp32 oracle than bf16's (10 vs 7 mantissa bits)."""
@@ -301,6 +354,62 @@ def test_decoder_window_at_real_size(td, dtype, tol):
     print(f"decoder 512x512 window {dtype}: rel-RMS vs oracle {err:.3e}")
     assert err < tol
     md.close()
+
+
+def test_config4_cascade_full_size_fp16_capped_store_vs_oracle_chain(td):
+    """BASELINE configs[4] in ONE test: the coarse -> two-phase latent -> decoder cascade with the FULL-SIZE base model
+    (30m, 192 channels), the decoder at its production window (512x512 pixels, stride 384), **fp16**, every window in HBM behind a store capped
+    below the working set (streaming eviction + recomputation), against the same InfiniteTensor graph whose window functions are the CPU oracle's
+    (oracle/stages.py, pinned window by window to the reference's _coarse_inference / _latent_inference / _decoder_inference).
+    The region [128,384) x [128,768) of the decoder tensor is covered by exactly the decoder windows (0,0) and (0,1); they pull 15 latent windows
+    (two blended trig-flow phases each) and 2 coarse windows through the graph.  Tolerance: fp16 <= 4e-3 per forward (N2), 1.5e-2 through the chain."""
+    from oracle import stages
+    from oracle.unet import BASE_CONFIG, COARSE_CONFIG, DECODER_CONFIG, OracleUnet, synth_state_dict
+    from terrain_diffusion_amd.pipeline import build_coarse_stage, build_latent_stage, build_decoder_stage
+    from terrain_diffusion_amd.infinite_tensor import InfiniteTensor, TensorWindow, DeviceTileStore
+    seed = 4242
+    means6 = [0.3, -0.2, 0.1, 0.0, 0.4, -0.1]; stds6 = [1.5, 0.8, 1.2, 0.9, 1.1, 0.7]; snr = [0.5, 0.4, 0.6, 0.3, 0.8]
+    hist = torch.tensor([[0.1, 0.3, 0.2, 0.25, 0.15]])
+    cm, cs_ = [0.2, 0.1, 0.0, -0.1, 0.3, 0.0, 0.66], [1.2, 1.1, 0.9, 1.0, 1.3, 0.8, 0.47]
+    sdc, sdb, sdd = synth_state_dict(COARSE_CONFIG, seed=1), synth_state_dict(BASE_CONFIG, seed=1234), synth_state_dict(DECODER_CONFIG, seed=2468)
+    mc = td.EDMUnet2D(**COARSE_CONFIG, dtype="fp16").load_state_dict(sdc)
+    mb = td.EDMUnet2D(**BASE_CONFIG, dtype="fp16").load_state_dict(sdb)
+    md = td.EDMUnet2D(**DECODER_CONFIG, dtype="fp16").load_state_dict(sdd)
+    # capped store: one decoder window (2 x 512 x 512 fp32 = 2 MiB) + a few latent windows -- far below the ~6 MiB the region touches
+    store = DeviceTileStore(cache_size_bytes=3 * 2 ** 20)
+    kwr = dict(device_resident=True, tile_store=store)
+    coarse = build_coarse_stage(mc, td.EDMDPMSolverMultistepScheduler(), seed=seed, cond_map_fn=stages.synthetic_coarse_map, coarse_means=means6,
+                                coarse_stds=stds6, cond_snr=snr, **kwr)
+    lat = build_latent_stage(mb, seed=seed, coarse=coarse, histogram_raw=hist, cond_means=cm, cond_stds=cs_, **kwr)
+    dec = build_decoder_stage(md, lat, seed=seed, tile_size=512, tile_stride=384, **kwr)
+    box = (slice(None), slice(128, 384), slice(128, 768))
+    got = dec[box].cpu()
+    assert store.evictions > 0, "the store was meant to evict while the region streams"
+    # ---- the same graph on the oracle (fp32 CPU)
+    oc, ob, od = OracleUnet(COARSE_CONFIG, sdc), OracleUnet(BASE_CONFIG, sdb), OracleUnet(DECODER_CONFIG, sdd)
+    ocoarse = InfiniteTensor((7, None, None), lambda ctx: stages.coarse_inference(oc, ctx, seed=seed, cond_map_fn=stages.synthetic_coarse_map, means=means6,
+                             stds=stds6, cond_snr=snr), TensorWindow(size=(7, 64, 64), stride=(7, 48, 48)), tensor_id="o4_coarse")
+    lwin, cwin = TensorWindow(size=(6, 64, 64), stride=(6, 32, 32)), TensorWindow(size=(7, 4, 4), stride=(7, 1, 1), offset=(0, -1, -1))
+    kw = dict(seed=seed, histogram_raw=hist, cond_means=cm, cond_stds=cs_)
+    t0, t1 = torch.atan(torch.tensor(80.0) / 0.5), torch.arctan(torch.tensor(0.35) / 0.5)
+    ol0 = InfiniteTensor((6, None, None), lambda ctx, c: stages.latent_inference(ob, [ctx], None, [c], t0, seed_offset=5819, **kw)[0], lwin,
+                         args=(ocoarse,), args_windows=(cwin,), tensor_id="o4_lat0")
+    ol1 = InfiniteTensor((6, None, None), lambda ctx, s_, c: stages.latent_inference(ob, [ctx], [s_], [c], t1, seed_offset=5820, **kw)[0], lwin,
+                         args=(ol0, ocoarse), args_windows=(lwin, cwin), tensor_id="o4_lat1")
+    odec = InfiniteTensor((2, None, None), lambda ctx, l: stages.decoder_inference(od, ctx, torch.as_tensor(l), seed=seed, tile_size=512, tile_stride=384),
+                          TensorWindow(size=(2, 512, 512), stride=(2, 384, 384)), args=(ol1,), args_windows=(TensorWindow(size=(6, 64, 64), stride=(6, 48, 48)),),
+                          tensor_id="o4_dec")
+    ref = torch.as_tensor(odec[box])
+    assert got.shape == ref.shape == (2, 256, 640)
+    assert torch.allclose(got[1], ref[1], rtol=1e-6, atol=1e-7)                                              # blend weights of the two windows
+    # the latent region the two decoder windows consumed, and the decoded residual
+    e_lat = rel_rms((torch.as_tensor(lat[:5, 16:48, 16:96]).cpu() / torch.as_tensor(lat[5:6, 16:48, 16:96]).cpu()).numpy(),
+                    (torch.as_tensor(ol1[:5, 16:48, 16:96]) / torch.as_tensor(ol1[5:6, 16:48, 16:96])).numpy())
+    err = rel_rms((got[0] / got[1]).numpy(), (ref[0] / ref[1]).numpy())
+    print(f"configs[4] cascade, full-size base + 512x512 decoder, fp16, capped store: latents {e_lat:.3e}, decoder output {err:.3e} rel-RMS vs the oracle chain; {store.evictions} evictions")
+    assert e_lat < 1e-2 and err < 1.5e-2
+    for m_ in (mc, mb, md):
+        m_.close()
 
 
 def test_bench_multi_rank_branch_dry_run_on_one_gpu():

@@ -56,12 +56,13 @@ def test_standard_normal_stream(td, golden, orc):
     g = golden("rng")
     got = td.standard_normal(123, (4097,))
     ref = g["normal_seed123_n4097"]
-    d = _ulp_diff(got, ref)
-    assert d.max() <= 1 and (d == 0).mean() >= 0.9999
+    # BIT-exact against the reference stream (round 3: 8 000 000 device normals of four seeds were compared with the host stream and not one
+    # differed, profiles/r03_noise_bit_exactness.txt -- the 1-ulp / 99.99 % allowance of rounds 1-2 was never needed)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), int(_ulp_diff(got, ref).max())
     # odd length, single value, longer than one round
     for seed, n in ((7, 1), (9, 2047), (11, 70001)):
-        d = _ulp_diff(td.standard_normal(seed, (n,)), orc["rng"].standard_normal(seed, (n,)))
-        assert d.max() <= 1 and (d == 0).mean() >= 0.9999, (seed, n)
+        a, b = td.standard_normal(seed, (n,)), orc["rng"].standard_normal(seed, (n,)).astype(np.float32)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (seed, n)
 
 
 def test_noise_patches(td, golden, orc):
@@ -70,13 +71,13 @@ def test_noise_patches(td, golden, orc):
              ("patch_coarse_48_m96", (43, 48, -96, 64, 64, 6, 64, 64)), ("patch_small", (7, -3, 61, 7, 9, 2, 16, 32)), ("patch_1x1", (7, -1, -1, 1, 1, 1, 8, 8))]
     for key, (seed, y0, x0, h, w, c, th, tw) in cases:
         got = td.gaussian_noise_patch(seed, y0, x0, h, w, channels=c, tile_h=th, tile_w=tw)
-        d = _ulp_diff(got, g[key])
-        assert got.shape == g[key].shape and d.max() <= 1 and (d == 0).mean() >= 0.999, key
+        # north_star: "bit-reproducible per (seed, tile-coord)" -- and bit-EQUAL to the reference's patches (negative coordinates, 4-tile straddles)
+        assert got.shape == g[key].shape and np.array_equal(np.ascontiguousarray(got).view(np.uint32), np.ascontiguousarray(g[key]).view(np.uint32)), (key, int(_ulp_diff(got, g[key]).max()))
     # batched windows share noise tiles; overlap consistency
     origins = [(32 * i, 32 * j) for i in range(3) for j in range(3)]
     b = td.gaussian_noise_patches(99, origins, 64, 64, channels=5, tile_h=64, tile_w=64, scale=2.0).cpu().numpy()
-    ref = np.stack([orc["rng"].gaussian_noise_patch(99, y, x, 64, 64, 5, 64, 64) for y, x in origins]) * 2.0
-    assert np.allclose(b, ref, rtol=2e-7, atol=0)
+    ref = np.stack([orc["rng"].gaussian_noise_patch(99, y, x, 64, 64, 5, 64, 64) for y, x in origins]).astype(np.float32) * np.float32(2.0)
+    assert np.array_equal(b, ref)   # scaling by 2 is exact in fp32
     assert np.array_equal(b[0][:, 32:, 32:], b[4][:, :32, :32])
 
 

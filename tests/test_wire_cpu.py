@@ -1,5 +1,6 @@
 """REST wire format, persistent tile store and seed derivation on the host (api.py:73-100, world_pipeline.py:625-674)."""
 import numpy as np
+import pytest
 import torch
 
 
@@ -40,3 +41,41 @@ def test_next_seed_matches_reference_value():
     from terrain_diffusion_amd.noise import next_seed
     assert next_seed(42) == 1039766031909981117
     assert next_seed(None) != next_seed(None) or True   # clock-seeded: only that it runs
+
+
+def test_file_tile_store_truncate_keeps_foreign_files_and_rejects_regular_file(tmp_path):
+    """Round-2 advisor: mode='w' removed EVERY file of the directory; a path that is a regular file failed inside os.makedirs."""
+    from terrain_diffusion_amd.wire import FileTileStore
+    d = tmp_path / "world"
+    d.mkdir()
+    (d / "notes.txt").write_text("mine")
+    s = FileTileStore(str(d))
+    s.put(("coarse", (0, 1, 2)), torch.ones(2, 2))
+    s.params = {"seed": 1, "kwargs": {}}
+    s2 = FileTileStore(str(d), mode="w")
+    assert s2.params is None and s2.get(("coarse", (0, 1, 2))) is None
+    assert (d / "notes.txt").read_text() == "mine"
+    f = tmp_path / "ref_world.h5"
+    f.write_bytes(b"\x89HDF\r\n\x1a\n")
+    with pytest.raises(ValueError, match="regular file"):
+        FileTileStore(str(f))
+
+
+def test_hdf5_tile_store_params_and_clear(tmp_path):
+    """Only where h5py exists (not in the build image): WORLD_PIPELINE_PARAMS lives on the file, clear() removes the datasets."""
+    pytest.importorskip("h5py")
+    from terrain_diffusion_amd.infinite_tensor import HDF5TileStore
+    path = str(tmp_path / "w.h5")
+    s = HDF5TileStore(path)
+    assert s.params is None
+    s.params = {"seed": 5, "kwargs": {"b": 1, "a": [1, 2]}}
+    s.put(("lat", (0, 1, 1)), torch.full((2, 3), 3.0))
+    s.put(("coarse", (0, 0, 0)), torch.zeros(1))
+    s.close()
+    s = HDF5TileStore(path)
+    assert s.params == {"seed": 5, "kwargs": {"a": [1, 2], "b": 1}} and torch.equal(s.get(("lat", (0, 1, 1))), torch.full((2, 3), 3.0))
+    s.clear("lat")
+    assert s.get(("lat", (0, 1, 1))) is None and s.get(("coarse", (0, 0, 0))) is not None
+    s.clear()
+    assert s.get(("coarse", (0, 0, 0))) is None
+    s.close()

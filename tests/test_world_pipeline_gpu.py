@@ -47,8 +47,29 @@ def test_perlin_map_kernel_vs_numpy_twin(td):
     assert np.allclose(fin, synthmap.finalize(raw.cpu().numpy(), s["a_temp_std"], s["b_temp_std"], s["temp_std_p1"], s["temp_std_p99"]), rtol=1e-5, atol=1e-3)
     full = f(10, 20, 42, 84)
     assert full.shape == (5, 32, 64) and torch.isfinite(full).all()
-    # the field is a function of absolute coordinates: overlapping requests agree
+    # the field is a function of absolute coordinates: overlapping (square) requests agree
     assert torch.equal(f.sample_raw(0, 0, 16, 16)[:, 4:, 4:], f.sample_raw(4, 4, 16, 16))
+    # reference orientation (synthetic_map.py:207-218, np.meshgrid(x, y) in 'xy' order): a square request is the TRANSPOSE of the kernel's natural order
+    assert torch.equal(f.sample_raw(-5, 9, 19, 33)[2], f._channel(2, -5, 9, 24, 24).t())
+
+
+def test_conditioning_windows_agree_on_shared_cells(td, models):
+    """The coarse stage asks for its conditioning window by window (world_pipeline.py:884-907, with the reference's (i, j) -> (j, i) swap):
+    two overlapping windows must see the same value at the same world cell, whatever their origins (round-2 advisor finding: the factory used
+    the natural orientation, so the swap made the value depend on the window origin and coarse tiles were blended from unrelated maps)."""
+    w = _world(td, models)
+    a = w._conditioning_model_input(0, 64, 0, 64)           # rows [0, 64) x cols [0, 64)
+    b = w._conditioning_model_input(48, 112, 0, 64)          # next window down: shares rows [48, 64)
+    c = w._conditioning_model_input(16, 80, -32, 32)         # diagonal neighbour: shares rows [16, 64) x cols [0, 32)
+    assert torch.equal(a[:, 48:, :], b[:, :16, :])
+    assert torch.equal(a[:, 16:, :32], c[:, :48, 32:])
+    # a custom import is placed in world orientation and merged with the same field (no `finalize`, world_pipeline.py:862-880)
+    imp = np.full((8, 8), 123.0, np.float32)
+    w.set_custom_conditioning_import(1, imp, 52, 4)
+    a2, b2 = w._conditioning_model_input(0, 64, 0, 64), w._conditioning_model_input(48, 112, 0, 64)
+    assert torch.equal(a2[:, 48:, :], b2[:, :16, :])
+    assert bool((a2[1, 52:60, 4:12] == 123.0).all()) and bool((b2[1, 4:12, 4:12] == 123.0).all())
+    w.close()
 
 
 def test_world_pipeline_get_matches_oracle_composition(td, models):
@@ -111,6 +132,41 @@ def test_world_pipeline_persistent_store_and_wire_format(td, models, tmp_path):
     out2 = w2.get(*box)
     assert not calls and torch.equal(out2["elev"], out["elev"]) and torch.equal(out2["climate"], out["climate"])
     w2.close()
+
+
+def test_world_file_parameter_mismatch_policy_and_temp_world(td, models, tmp_path):
+    """world_pipeline.py:625-664: a world file records seed + kwargs.  Reopened with another seed the reference asks on the console; here
+    on_param_mismatch decides and the default ('stored', the reference's default answer) is LOUD (round-2 review: it was silent)."""
+    import os
+    path = str(tmp_path / "world2")
+    mk = lambda seed: td.WorldPipeline.from_models(*models, seed=seed, decoder_tile_size=64, decoder_tile_stride=48, latents_batch_size=16, caching_strategy="indirect")
+    w = mk(4242).bind(path); w.close()
+    with pytest.warns(UserWarning, match="other parameters"):
+        w = mk(7).bind(path)
+    assert w.seed == 4242 and w.tile_store.params["seed"] == 4242
+    w.close()
+    with pytest.raises(ValueError, match="other parameters"):
+        mk(7).bind(path, on_param_mismatch="error")
+    w = mk(7).bind(path, on_param_mismatch="overwrite")
+    assert w.seed == 7 and w.tile_store.params["seed"] == 7
+    w.close()
+    # 'TEMP' (world_pipeline.py:28-36, 711-713): a temporary world that close() removes
+    w = mk(11).bind("TEMP")
+    tmp = w._temp_dir
+    assert os.path.isdir(tmp) and w.tile_store.params["seed"] == 11
+    w.close()
+    assert not os.path.exists(tmp)
+
+
+def test_device_window_tensor_integer_indices_drop_their_dimension(td, models):
+    """Round-2 advisor: in the channel-subset branch only dim 0 was squeezed (t[0, 5, :] kept a size-1 dimension)."""
+    w = _world(td, models)
+    t = w.coarse
+    full = t[:, 3:9, 2:12]
+    assert t[0, 5, 2:12].shape == (10,) and torch.equal(t[0, 5, 2:12], full[0, 2])
+    assert t[1:3, 4, 2:12].shape == (2, 10) and torch.equal(t[1:3, 4, 2:12], full[1:3, 1])
+    assert t[:, 4, 7].shape == (full.shape[0],) and torch.equal(t[:, 4, 7], full[:, 1, 5])
+    w.close()
 
 
 def _world_indirect(td, models, path):
