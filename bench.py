@@ -32,7 +32,7 @@ WEIGHT_BYTES_BF16 = 253_688_037 * 2  # algorithmic minimum HBM bytes per forward
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-PROFILE_JSON = os.path.join(ROOT, "profiles", "r02_hbm_traffic_and_mfma_util.json")
+PROFILE_JSON = os.path.join(ROOT, "profiles", "r03_hbm_traffic_and_mfma_util.json")   # stamped with the library build id it was collected with
 
 # terrain-diffusion-30m base model (configs/diffusion_base/30m/diffusion_192-3.cfg:54-68)
 BASE_CONFIG = dict(image_size=512, in_channels=5, out_channels=5, model_channels=192, model_channel_mults=[1, 2, 3, 4], layers_per_block=3,
@@ -194,16 +194,8 @@ def main():
         result["seam"] = {"bytes_total_per_step": seam.get("seam_bytes_total", 0), "bytes_sent_rank0_per_step": seam.get("seam_bytes_sent", 0),
                           "exchange_ms_per_step_rank0": round(seam.get("exchange_s", 0.0) / max(1, args.steps) * 1e3, 3),
                           "windows_rank0": seam.get("windows_this_rank"), "backend": ("gloo through host memory, all ranks on ONE GPU (dry run)" if one_gpu else "nccl (RCCL)") if world > 1 else "none (1 rank)"}
-        # the N = 1 DRIVER line is another workload (grid8, configs[2]); strong-scaling efficiency of THIS workload is value / (N x the committed
-        # one-rank measurement of the same workload), not value / (N x the grid8 number)
-        ref = os.path.join(ROOT, "profiles", "r02_bench_grid32_n1.json")
-        if world > 1 and os.path.exists(ref) and args.dtype == "bf16" and E == 20:
-            try:
-                one = json.loads(open(ref).read().strip().splitlines()[-1])
-                result["strong_scaling"] = {"one_rank_value_same_workload": one["value"], "source": os.path.relpath(ref, ROOT),
-                                            "speedup_vs_one_rank": round(value / one["value"], 3), "efficiency": round(value / one["value"] / world, 4)}
-            except Exception:
-                pass
+        # strong-scaling efficiency of THIS workload needs an N = 1 point of the same workload: the N = 1 line carries one, measured live in
+        # the same run ("strong_scaling_anchor"); nothing is read from committed files
 
     if rank == 0:
         peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "fp16") else PEAK_F32_TFLOPS
@@ -246,15 +238,27 @@ def main():
                                                "the two lanes' kernels overlap pairwise: traced durations are up to 2x avg_launch_us and their sum exceeds the wall time."})
             else:
                 roof.update({"achieved": roof["end_to_end_achieved"], "frac": roof["end_to_end_frac"]})
-            if os.path.exists(PROFILE_JSON) and workload in ("grid8", "tiles") and tiles_per_step == 64 and args.dtype == "bf16":
-                # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled per the
-                # MI355X guide's gfx950 correction, + WRITE_SIZE); not re-measured live (PMC collection needs rocprofv3)
-                tj = json.load(open(PROFILE_JSON))["kernels"]
-                ks_ = [v for k_, v in tj.items() if ("conv_glds_kernel" in k_ or "conv_pp_kernel" in k_) and v.get("dispatches") and "hbm_read_bytes_per_launch" in v]
-                n_ = sum(v["dispatches"] for v in ks_)
-                if n_:
-                    roof["traffic"] = round(sum(v["dispatches"] * (v["hbm_read_bytes_per_launch"] + v.get("hbm_write_bytes_per_launch", 0)) for v in ks_) / n_)
-                    roof["traffic_source"] = os.path.relpath(PROFILE_JSON, ROOT)
+            if workload in ("grid8", "tiles") and tiles_per_step == 64 and args.dtype == "bf16":
+                # HBM bytes per launch come from rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled per the MI355X guide's gfx950
+                # correction, + WRITE_SIZE); PMC collection needs rocprofv3, so they are not re-measured here -- but they are only reported when the
+                # counter file was collected with the very library that is loaded now (td_build_id stamp), never stale
+                from terrain_diffusion_amd._lib import lib as _lib
+                bid = _lib().td_build_id().decode()
+                roof["library_build_id"] = bid
+                if not os.path.exists(PROFILE_JSON):
+                    roof["traffic_note"] = f"no counter file {os.path.relpath(PROFILE_JSON, ROOT)}"
+                else:
+                    pj = json.load(open(PROFILE_JSON))
+                    if pj.get("library_build_id") != bid:
+                        roof["traffic_note"] = (f"{os.path.relpath(PROFILE_JSON, ROOT)} was collected with library build {pj.get('library_build_id')}, the loaded library is "
+                                                f"{bid}: stale counters are not reported (re-run tools/collect_profiles.sh)")
+                    else:
+                        tj = pj["kernels"]
+                        ks_ = [v for k_, v in tj.items() if ("conv_glds_kernel" in k_ or "conv_pp_kernel" in k_) and v.get("dispatches") and "hbm_read_bytes_per_launch" in v]
+                        n_ = sum(v["dispatches"] for v in ks_)
+                        if n_:
+                            roof["traffic"] = round(sum(v["dispatches"] * (v["hbm_read_bytes_per_launch"] + v.get("hbm_write_bytes_per_launch", 0)) for v in ks_) / n_)
+                            roof["traffic_source"] = os.path.relpath(PROFILE_JSON, ROOT)
         else:
             roof.update({"achieved": roof["end_to_end_achieved"], "frac": roof["end_to_end_frac"]})
         result["roofline"] = roof
@@ -271,6 +275,26 @@ def main():
             hbm = E * WEIGHT_BYTES_BF16 / lat / 1e9
             result["roofline_single_tile"] = {"bound": "hbm", "achieved": round(hbm, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(hbm / PEAK_HBM_GBS, 4),
                                               "note": f"algorithmic bytes = {E} forwards x {WEIGHT_BYTES_BF16} B of bf16 weights (activations of one tile are negligible)"}
+
+        if world == 1 and not args.no_latency and workload == "grid8" and args.dtype == "bf16":
+            # N = 1 point of the STRONG-scaling workload the driver runs at N > 1 (grid32, BASELINE configs[3]): one full step, timed live in this
+            # run with the same engine options the sharded run uses, so that the 1 -> N curve has a same-run, same-node anchor
+            from terrain_diffusion_amd.parallel import sample_base_diffusion_sharded
+            eng.set_option("batch_invariant", 1); eng.set_option("dual_stream", 1)
+            try:
+                one_step(30_000, 64, "tiles"); sync()          # builds the batch-invariant plans and graphs of the two 32-window lanes
+                nt32 = len(_tile_starts(1056, 64, 32))
+                cond32 = synthetic_cond_grid(nt32, nt32, device=dev)
+                a0 = time.perf_counter()
+                sample_base_diffusion_sharded(model, sch, (1, 5, 1056, 1056), cond32, noise_seed=42 + 5819, noise_origin=(0, 4096 * 31_000), max_batch=64, stats={}, **kw)
+                sync()
+                adt = time.perf_counter() - a0
+                mp32 = (1056 * 8) ** 2 / 1e6
+                result["strong_scaling_anchor"] = {"workload": "grid32 (BASELINE configs[3]) on ONE rank: 32x32 windows, 1056x1056 latents, 20 steps, batch-invariant, two sampler lanes",
+                                                   "value": round(mp32 / adt, 4), "unit": "MP/s", "ms_per_step": round(adt * 1e3, 2), "steps_timed": 1,
+                                                   "note": "divide an N > 1 driver line's value by N x this to get the strong-scaling efficiency of that workload"}
+            finally:
+                eng.set_option("batch_invariant", 0); eng.set_option("dual_stream", 0)
 
         if world == 1 and not args.no_cpu_baseline:
             # CPU baseline = the oracle (CPU restatement pinned to the reference) on this host's cores, bounded sample

@@ -55,6 +55,10 @@ typedef struct td_unet_config {
 
 const char* td_last_error(void);
 int td_version(void);
+/* 16 hex digits identifying the kernel sources this library was built from (sha256 over the files of terrain_diffusion_amd/csrc and this header, stamped by
+ * __graft_entry__.build()); bench.py ties committed rocprofv3 counter files to the library that is actually loaded with it.  No reference
+ * counterpart (the reference has no native code). */
+const char* td_build_id(void);
 
 /* ---- engine ----------------------------------------------------------------------------------------------- */
 int td_engine_create(int device_id, td_engine** out);
@@ -62,8 +66,17 @@ void td_engine_destroy(td_engine* e);
 int td_engine_synchronize(td_engine* e);
 /* raw hipStream_t the engine launches on (for timing with HIP events on the right stream) */
 void* td_engine_stream(td_engine* e);
+/* Caller-supplied stream: every later call enqueues on `hip_stream` (a hipStream_t created by the caller -- e.g. the
+ * torch.cuda.Stream that also carries the caller's own kernels and its RCCL transfers; NOT the legacy NULL stream, which cannot be captured
+ * into the engine's hipGraphs); NULL restores the engine's own stream.  The old stream is drained first.  By default every call still returns
+ * with its results complete; with td_engine_set_option(e, "async", 1) a call whose buffers are all device pointers (td_sample_edm*,
+ * td_sample_consistency*, td_blend_normalize) only ENQUEUES its work, ordered with whatever else the caller puts on that stream, and
+ * td_engine_synchronize() (or the caller's own stream synchronisation followed by it) releases the calls' staging buffers.  The reference
+ * gets the same ordering from torch's current-stream semantics (world_pipeline.py:941-949 runs model and scheduler ops on one stream). */
+int td_engine_set_stream(td_engine* e, void* hip_stream);
 /* knobs: "graph"=0/1, "splitk"=0/1, "batch_invariant"=0/1, "solver_order"=1/2 (EDMDPMSolverMultistepScheduler.config.solver_order),
- * "glds_variant"=-1/0/1 and "glds_bn"=0/96/128 (force the conv tile shape: test hook), "plan_cache_mb", "plan_cache_max", "profile"=0/1 */
+ * "glds_variant"=-1/0/1 and "glds_bn"=0/96/128 (force the conv tile shape: test hook), "plan_cache_mb", "plan_cache_max", "profile"=0/1,
+ * "async"=0/1 (see td_engine_set_stream), "walk_alternate"=0/1 (every second conv walks its workgroup grid backwards: speed only) */
 int td_engine_set_option(td_engine* e, const char* key, int64_t value);
 
 /* With option "profile"=1 the samplers run eagerly (no graph) with HIP events recorded on the engine stream around every

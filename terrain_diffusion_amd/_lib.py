@@ -26,10 +26,12 @@ _P = C.c_void_p
 _SIGS = {
     "td_last_error": (C.c_char_p, []),
     "td_version": (C.c_int, []),
+    "td_build_id": (C.c_char_p, []),
     "td_engine_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "td_engine_destroy": (None, [_P]),
     "td_engine_synchronize": (C.c_int, [_P]),
     "td_engine_stream": (_P, [_P]),
+    "td_engine_set_stream": (C.c_int, [_P, _P]),
     "td_engine_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "td_engine_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     "td_engine_profile_read_glds": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),

@@ -66,7 +66,13 @@ def run_cascade(args, eng, dev, rank, world):
     ops = eng.profile_ops()
     conv_ms, conv_n, other_ms, other_n = eng.profile_read(reset=True)
     eng.set_option("profile", 0)
-    by_level = {}
+    import re
+    by_level, mb_level = {}, {}
+    for label, ms, n in ops:
+        mres = re.search(r"\[(\d+x\d+) .* mb([0-9.]+)\]", label)
+        if mres:
+            a = mb_level.setdefault(mres.group(1), [0.0, 0.0])
+            a[0] += float(mres.group(2)) * n; a[1] += ms
     for label, ms, n in ops:
         key = "coarse+latent 64x64 and below" if any(s in label for s in ("[64x64", "[32x32", "[16x16", "[8x8")) else "decoder levels " + label[label.find("[") + 1:].split(" ")[0] if "[" in label else "other"
         by_level[key] = by_level.get(key, 0.0) + ms
@@ -85,7 +91,13 @@ def run_cascade(args, eng, dev, rank, world):
                      "frac": round(tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
                      "note": "end to end over the algorithmic 15.24 TFLOP per decoded MP (recomputed evicted windows are NOT counted as useful work)",
                      "one_request_conv_kernel_ms": round(conv_ms, 2), "one_request_other_kernel_ms": round(other_ms, 2),
-                     "one_request_kernel_ms_by_resolution": {k: round(v, 2) for k, v in sorted(by_level.items())}},
+                     "one_request_kernel_ms_by_resolution": {k: round(v, 2) for k, v in sorted(by_level.items())},
+                     # achieved HBM GB/s of the conv path by resolution level: algorithmic megabytes of the level's launches (sources, residual, outputs and
+                     # weights once each, `mb` of the engine's per-op profile) / their kernel time.  The decoder's 64-channel 512x512 level is the
+                     # activation-bound one (~288 FLOP/B, below the 312 FLOP/B ridge of 2.5 PF over 8 TB/s)
+                     "hbm_gbps_by_resolution": {k: round(v[0] / v[1], 1) for k, v in sorted(mb_level.items()) if v[1] > 0},
+                     "hbm_gbps_decoder_512x512": round(mb_level["512x512"][0] / mb_level["512x512"][1], 1) if mb_level.get("512x512", [0, 0])[1] > 0 else None,
+                     "hbm_peak_gbps": 8000.0},
     }
     if rank == 0:
         print(json.dumps(result), flush=True)

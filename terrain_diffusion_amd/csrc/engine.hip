@@ -93,8 +93,10 @@ struct td_engine {
     int device = 0;
     int n_cus = 256;
     void* zeros = nullptr;     // 4 KiB of zeros: halo source of the LDS-DMA patch staging (conv_pp.hip)
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // the stream every call enqueues on: the engine's own, or the caller's (td_engine_set_stream)
+    hipStream_t own_stream = nullptr;
     hipStream_t stream2 = nullptr;  // second lane of the batched EDM sampler (sample_edm_impl): two half-batches run concurrently
+    std::vector<std::unique_ptr<struct DevBuf>> deferred;  // option "async": staging buffers of enqueued calls, released by td_engine_synchronize
     std::map<std::string, int64_t> opt;
     // scratch for I/O staging
     std::vector<Buf> keep;
@@ -133,6 +135,20 @@ static int out_finish(td_engine* e, const OutStage& st) {
         HIP_TRY(hipMemcpyAsync(st.host, st.dev, st.bytes, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
+    return TD_OK;
+}
+
+// End of a C-ABI call.  Default: the call is synchronous (results complete on return).  With engine option "async" = 1 and only device
+// pointers involved, the work stays enqueued on e->stream -- typically the caller's own stream (td_engine_set_stream), so that it is ordered
+// with the caller's other GPU work without a host synchronisation -- and the call's staging buffers are parked until td_engine_synchronize.
+static int end_call(td_engine* e, std::vector<Buf>& hold, bool all_device) {
+    if (all_device && e->option("async", 0) != 0) {
+        if (e->deferred.size() > 256) { HIP_TRY(hipStreamSynchronize(e->stream)); e->deferred.clear(); }
+        for (auto& b : hold) e->deferred.push_back(std::move(b));
+        hold.clear();
+        return TD_OK;
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return TD_OK;
 }
 
@@ -917,8 +933,14 @@ static int run_unet(td_unet* u, Plan& pl, int step) {
         mark();
         hipError_t e = op.flavor == 3 ? launch_conv_pp(p, u->dt, op.bn, u->eng->n_cus, st)
                        : op.flavor == 2 ? launch_conv_glds(p, u->dt, op.narrow, op.bn, op.glds_variant, st) : launch_conv(p, u->dt, op.narrow, op.bn, 0, st);
-        mark(); if (prof) { ev_kind.push_back(0); char tag[96]; double gf_ = 0.0; for (int si_ = 0; si_ < p.nseg; ++si_) gf_ += (double)p.seg[si_].C * p.seg[si_].taps; gf_ *= 2.0 * p.N * p.H * p.W * p.Cout * 1e-9;  /* algorithmic GFLOP of this launch */
-            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 3 ? "p" : op.flavor == 2 ? (op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_); ev_label.push_back(op.label + tag);
+        mark(); if (prof) { ev_kind.push_back(0); char tag[128]; double gf_ = 0.0; for (int si_ = 0; si_ < p.nseg; ++si_) gf_ += (double)p.seg[si_].C * p.seg[si_].taps; gf_ *= 2.0 * p.N * p.H * p.W * p.Cout * 1e-9;  /* algorithmic GFLOP of this launch */
+            /* algorithmic HBM megabytes of this launch: every source tensor once (at ITS resolution), the residual once, the outputs once, the weights once */
+            double mb_ = 0.0; const double es_ = (double)u->esize();
+            for (int si_ = 0; si_ < p.nseg; ++si_) mb_ += (double)p.N * p.seg[si_].Hs * p.seg[si_].Ws * p.seg[si_].C * es_ + (double)p.seg[si_].C / 64.0 * p.seg[si_].taps * p.CoutPad * 128.0 * (es_ / 2.0);
+            if (p.res) mb_ += (double)p.N * p.res_Hs * p.res_Ws * p.Cout * es_;
+            mb_ += (double)p.N * p.H * p.W * p.Cout * (p.out_f32 ? 4.0 : es_) * (p.out2 ? 2.0 : 1.0);
+            mb_ *= 1e-6;
+            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f mb%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 3 ? "p" : op.flavor == 2 ? (op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_, mb_); ev_label.push_back(op.label + tag);
             double kk = 0; for (int s_ = 0; s_ < p.nseg; ++s_) kk += (double)p.seg[s_].C * p.seg[s_].taps;
             ev_flop.push_back(op.flavor >= 2 ? 2.0 * p.N * p.H * p.W * (double)p.Cout * kk : 0.0); }
         if (e != hipSuccess) return fail(TD_ERR_HIP, "conv launch " + op.label + ": " + hipGetErrorString(e));
@@ -933,6 +955,10 @@ extern "C" {
 
 const char* td_last_error(void) { return g_err.c_str(); }
 int td_version(void) { return 1; }
+#ifndef TD_CSRC_SHA
+#define TD_CSRC_SHA "unstamped"
+#endif
+const char* td_build_id(void) { return TD_CSRC_SHA; }
 
 int td_engine_create(int device_id, td_engine** out) {
     if (!out) return fail(TD_ERR_ARG, "null out");
@@ -944,6 +970,7 @@ int td_engine_create(int device_id, td_engine** out) {
     e->device = device_id;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) e->n_cus = prop.multiProcessorCount; }
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    e->own_stream = e->stream;
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipMalloc(&e->zeros, 4096);
     if (err == hipSuccess) err = hipMemset(e->zeros, 0, 4096);
@@ -961,8 +988,16 @@ void td_engine_destroy(td_engine* e) {
     delete e;
 }
 int td_engine_synchronize(td_engine* e) {
-    DevGuard dg_(e->device); HIP_TRY(hipStreamSynchronize(e->stream)); return TD_OK; }
+    DevGuard dg_(e->device); HIP_TRY(hipStreamSynchronize(e->stream)); e->deferred.clear(); return TD_OK; }
 void* td_engine_stream(td_engine* e) { return (void*)e->stream; }
+int td_engine_set_stream(td_engine* e, void* hip_stream) {
+    if (!e) return fail(TD_ERR_ARG, "null engine");
+    DevGuard dg_(e->device);
+    HIP_TRY(hipStreamSynchronize(e->stream));   // nothing of the old stream may be pending when the order of work changes hands
+    e->deferred.clear();
+    e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    return TD_OK;
+}
 int td_engine_set_option(td_engine* e, const char* key, int64_t value) {
     if (!e || !key) return fail(TD_ERR_ARG, "null");
     e->opt[key] = value;
@@ -1276,10 +1311,9 @@ static int sample_edm_impl(td_unet* u, td_unet* guide, float gscale, int n, int 
     const bool concurrent = e->option("profile", 0) == 0;  // profile mode times every launch with events on ONE stream: the lanes run one after the other
     if (!dual) {
         int rc = sample_edm_lane(u, guide, gscale, n, H, W, n_steps, sigmas_host, sigma_data, cond, cond_img, cimg, x, 0, hold);
-        hipError_t se = hipStreamSynchronize(e->stream);  // the caller's framework uses other streams: results must be complete on return
-        if (rc) return rc;
-        HIP_TRY(se);
-        return TD_OK;
+        if (rc) { (void)hipStreamSynchronize(e->stream); return rc; }
+        // default: results complete on return (the caller's framework uses other streams); option "async": left enqueued on e->stream
+        return end_call(e, hold, is_device_ptr(x) && (!cond || is_device_ptr(cond)) && (!cond_img || is_device_ptr(cond_img)));
     }
     const int nA = n / 2, nB = n - nA, C = u->cfg.out_channels;
     const size_t HW = (size_t)H * W;
@@ -1338,8 +1372,7 @@ int td_sample_consistency_img(td_unet* u, int n, int H, int W, float t, float si
     hipLaunchKernelGGL(consistency_post_kernel, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->xt->p, (const float*)pl->F, (float*)os.dev, n, C, HW, 8, ct, sn, sigma_data);
     HIP_TRY(hipGetLastError());
     if ((rc = out_finish(e, os))) return rc;
-    HIP_TRY(hipStreamSynchronize(st));
-    return TD_OK;
+    return end_call(e, hold, !os.host && is_device_ptr(z) && (!sample || is_device_ptr(sample)) && (!cond || is_device_ptr(cond)) && (!cond_img || is_device_ptr(cond_img)));
 }
 
 int td_sample_consistency(td_unet* u, int n, int H, int W, float t, float sigma_data, const float* sample, const float* z, const float* cond, float* out) {
@@ -1510,8 +1543,7 @@ int td_blend_normalize(td_engine* e, const float* canvas, int C, int Hc, int Wc,
     hipLaunchKernelGGL(blend_normalize_kernel, grid1((size_t)Hc * Wc), dim3(256), 0, e->stream, (const float*)dc, (float*)os.dev, C, Hc * Wc, scale);
     HIP_TRY(hipGetLastError());
     if ((rc = out_finish(e, os))) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    return TD_OK;
+    return end_call(e, hold, !os.host && is_device_ptr(canvas));
 }
 
 // ---- output composition

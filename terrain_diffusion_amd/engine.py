@@ -46,6 +46,30 @@ class Engine:
     def stream(self):
         return lib().td_engine_stream(self._h)
 
+    def set_stream(self, stream=None):
+        """Caller-supplied stream (td_engine_set_stream): a torch.cuda.Stream / raw hipStream_t handle, or None for the engine's own stream.
+        torch's DEFAULT stream is the legacy NULL stream, which hipGraph capture refuses: pass a stream you created."""
+        h = getattr(stream, "cuda_stream", stream)
+        if stream is not None and not h:
+            raise ValueError("the legacy default (NULL) stream cannot carry the engine's captured graphs: create a torch.cuda.Stream()")
+        check(lib().td_engine_set_stream(self._h, C.c_void_p(int(h)) if h else None))
+
+    def on_stream(self, stream, asynchronous=True):
+        """Context manager: run the engine on `stream`; with asynchronous=True calls on device tensors only enqueue (option "async")."""
+        eng = self
+
+        class _Ctx:
+            def __enter__(self_):
+                eng.set_stream(stream)
+                eng.set_option("async", 1 if asynchronous else 0)
+                return eng
+
+            def __exit__(self_, *exc):
+                eng.set_option("async", 0)
+                eng.set_stream(None)     # drains the stream and releases the staging buffers
+                return False
+        return _Ctx()
+
     def close(self):
         if self._h:
             lib().td_engine_destroy(self._h)

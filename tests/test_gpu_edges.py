@@ -219,3 +219,39 @@ def test_forward_and_checkpoint_argument_validation(td):
     with pytest.raises(ValueError):
         m(x[:, :3], torch.tensor([0.3]), [c])
     m.close()
+
+
+def test_caller_supplied_stream_orders_engine_work_without_host_sync(td):
+    """td_engine_set_stream + option "async" (VERDICT round 2 item 8): a producer kernel, the engine's sampler and a consumer kernel
+    are enqueued on ONE caller stream without any host synchronisation in between; the result equals the default synchronous path bit for bit.
+    A delay kernel in front keeps the stream busy while everything is enqueued, so a missing dependency would read unfinished data."""
+    import torch
+    from oracle.unet import synth_state_dict, tiny_config
+    from terrain_diffusion_amd.engine import get_engine
+    from terrain_diffusion_amd.sampling import sample_tiles_edm
+    eng = get_engine("cuda")
+    cfg = tiny_config(64, 1)
+    m = td.EDMUnet2D(**cfg, dtype="bf16").load_state_dict(synth_state_dict(cfg, seed=77))
+    sch = td.EDMDPMSolverMultistepScheduler()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    base = torch.randn(4, 5, 16, 16, device="cuda", generator=g)
+    cond = torch.randn(4, m.cond_row_len if hasattr(m, "cond_row_len") else 58, device="cuda", generator=g)
+    sch.set_timesteps(6)
+    ref_in = (base * 3.0 + 1.0).contiguous()
+    ref = sample_tiles_edm(m, sch, ref_in.clone(), cond, 6) * 0.5
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with pytest.raises(ValueError):
+        eng.set_stream(torch.cuda.default_stream())
+    big = torch.randn(4096, 4096, device="cuda")
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), eng.on_stream(s):
+        for _ in range(20):
+            big = big @ big * 1e-3                      # ~ms of queued work ahead of the producer
+        x = (base * 3.0 + 1.0).contiguous()             # producer on s
+        y = sample_tiles_edm(m, sch, x, cond, 6)        # engine: enqueued on s, returns without waiting
+        out = y * 0.5                                   # consumer on s
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert eng.stream != s.cuda_stream                  # the context restored the engine's own stream
+    m.close()

@@ -46,7 +46,12 @@ for k, cs in cnt.items():
         mfma = g("SQ_INSTS_VALU_MFMA_MOPS_BF16") / 64.0   # MOPS counter: 64 per 32x32x16 bf16 MFMA (32768 flop / 512)
         e["valu_per_mfma"] = round((g("SQ_INSTS_VALU") - mfma) / mfma, 2) if mfma else None
     kern[k] = e
-json.dump({"note": "rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-latency` (batch 64 x 20 solver steps per bench step). FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced stream); WRITE_SIZE uncalibrated; units KB -> bytes x1024. mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs).", "kernels": kern}, open(out + "/hbm_traffic_and_mfma_util.json", "w"), indent=1)
+import sys
+sys.path.insert(0, R)
+import __graft_entry__ as ge
+import ctypes as C
+_l = C.CDLL(ge.LIB); _l.td_build_id.restype = C.c_char_p
+json.dump({"csrc_sha16": ge.csrc_sha16(), "library_build_id": _l.td_build_id().decode(), "note": "rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-latency` (batch 64 x 20 solver steps per bench step). FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced stream); WRITE_SIZE uncalibrated; units KB -> bytes x1024. mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs).", "kernels": kern}, open(out + "/hbm_traffic_and_mfma_util.json", "w"), indent=1)
 print(open(out + "/kernel_trace_summary.csv").read()[:1500])
 PY
 rm -rf $OUT/kt $OUT/pmc_*/  # raw traces are large; the summaries are what gets committed
