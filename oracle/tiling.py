@@ -176,3 +176,91 @@ def sample_base_consistency_tiled(model, shape, cond_inputs, *, intermediate_t=0
                 output_weights[..., i0:i0 + tile_size, j0:j0 + tile_size] += weights
         sample = output / output_weights
     return sample / sigma_data
+
+
+# ---- bounded decoder / coarse samplers (test infrastructure, CPU restatements) -------------------------------------------------------------
+def _edm_tile(model, x, tile_cond_img, cond_list, steps, sigma_data=0.5, sigma_min=0.002, sigma_max=80.0, rho=7.0):
+    """`steps` DPM-Solver++(2M) steps on one tile batch with conditioning-image channels concatenated after the sample channels
+    (sample_diffusion_decoder.py:103-118, sample_coarse.py:104-117; a fresh step index per tile, see the note in the callers)."""
+    sigmas, _ = schedule.karras_sigmas(steps, sigma_min, sigma_max, rho)
+    orders = schedule.solver_orders(steps)
+    m_prev = None
+    for i in range(steps):
+        sigma = sigmas[i]
+        xin = torch.cat([schedule.precondition_inputs(x, sigma, sigma_data), tile_cond_img], dim=1)
+        cn = schedule.trigflow_t(sigma.view(-1).expand(x.shape[0]), sigma_data)
+        x, m_prev = schedule.dpm_step(sigmas, i, orders[i], x, model(xin, cn, cond_list), m_prev, sigma_data)
+    return x
+
+
+@torch.no_grad()
+def sample_decoder_diffusion_tiled(model, cond_img, noise, tile_size=None, tile_stride=None, *, num_steps, sigma_data=0.5):
+    """sample_diffusion_decoder.py:44-125 (no guidance, no score scaling).  The reference sets the timesteps once outside its tile loop and its
+    scheduler's step index then runs off the table on the second tile (IndexError): every tile gets a fresh schedule here, which is what a
+    single-tile call of the reference does."""
+    b, c, h, w = noise.shape
+    cond_img = cond_img.to(noise.dtype)
+    if cond_img.shape[-2:] != (h, w):
+        cond_img = torch.nn.functional.interpolate(cond_img, size=(h, w), mode="nearest")
+    tile_size = min(h, w) if tile_size is None else tile_size
+    tile_stride = tile_size if tile_stride is None else tile_stride
+    weights = linear_weight_window(tile_size)[None, None]
+    out, out_w = torch.zeros_like(noise), torch.zeros_like(noise)
+    for i0 in tile_starts(h, tile_size, tile_stride):
+        for j0 in tile_starts(w, tile_size, tile_stride):
+            sl = (..., slice(i0, i0 + tile_size), slice(j0, j0 + tile_size))
+            out[sl] += _edm_tile(model, noise[sl], cond_img[sl], [], num_steps, sigma_data) * weights
+            out_w[sl] += weights
+    return out / out_w
+
+
+@torch.no_grad()
+def sample_decoder_consistency_tiled(model, cond_img, noise, tile_size=None, tile_stride=None, *, intermediate_t=(), sigma_data=0.5, sigma_max=80.0):
+    """sample_diffusion_decoder.py:129-211."""
+    b, c, h, w = noise.shape
+    cond_img = cond_img.to(noise.dtype)
+    if cond_img.shape[-2:] != (h, w):
+        cond_img = torch.nn.functional.interpolate(cond_img, size=(h, w), mode="nearest")
+    tile_size = min(h, w) if tile_size is None else tile_size
+    tile_stride = tile_size if tile_stride is None else tile_stride
+    weights = linear_weight_window(tile_size)[None, None]
+    out, out_w = torch.zeros_like(noise), torch.zeros_like(noise)
+    ts = [torch.atan(torch.as_tensor(sigma_max / sigma_data, dtype=noise.dtype))] + [torch.tensor(t, dtype=noise.dtype) for t in intermediate_t]
+    for i0 in tile_starts(h, tile_size, tile_stride):
+        for j0 in tile_starts(w, tile_size, tile_stride):
+            sl = (..., slice(i0, i0 + tile_size), slice(j0, j0 + tile_size))
+            samples = torch.zeros((b, c, tile_size, tile_size), dtype=noise.dtype)
+            for t_scalar in ts:
+                t = t_scalar.view(1, 1, 1, 1).expand(b, 1, 1, 1)
+                x_t = torch.cos(t) * samples + torch.sin(t) * (noise[sl] * sigma_data)
+                pred = -model(torch.cat([x_t / sigma_data, cond_img[sl]], dim=1), t.flatten(), [])
+                samples = torch.cos(t) * x_t - torch.sin(t) * sigma_data * pred
+            out[sl] += samples * weights
+            out_w[sl] += weights
+    return out / out_w / sigma_data
+
+
+@torch.no_grad()
+def sample_coarse_tiled(model, cond_img, cond_snr, *, steps, cond_noise, init_noise, out_channels=6, tile_size=None, tile_stride=None, sigma_data=0.5):
+    """sample_coarse.py:29-125 with the two torch.randn draws replaced by the given tensors (cond_noise like cond_img; init_noise: one
+    (b, out_channels, T, T) per tile, row-major)."""
+    b, c_cond, h, w = cond_img.shape
+    tile_size = w if tile_size is None else tile_size
+    tile_stride = tile_size if tile_stride is None else tile_stride
+    weights = linear_weight_window(tile_size)[None, None]
+    out = torch.zeros((b, out_channels, h, w))
+    out_w = torch.zeros_like(out)
+    snr = torch.as_tensor(cond_snr, dtype=torch.float32)
+    t = torch.atan(snr)
+    cond_list = [v.reshape(-1) for v in torch.log(torch.tan(t) / 8.0).transpose(0, 1)]
+    cond_img = torch.cos(t).view(1, -1, 1, 1) * cond_img + torch.sin(t).view(1, -1, 1, 1) * cond_noise
+    sigma0 = schedule.karras_sigmas(steps)[0][0]
+    k = 0
+    for i0 in tile_starts(h, tile_size, tile_stride):
+        for j0 in tile_starts(w, tile_size, tile_stride):
+            sl = (..., slice(i0, i0 + tile_size), slice(j0, j0 + tile_size))
+            x = _edm_tile(model, init_noise[k] * sigma0, cond_img[sl], cond_list, steps, sigma_data) / sigma_data
+            out[sl] += x * weights
+            out_w[sl] += weights
+            k += 1
+    return out / out_w

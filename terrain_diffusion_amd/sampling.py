@@ -256,3 +256,146 @@ def sample_base_consistency(model, scheduler, shape, cond_inputs, *, cond_means,
             blend_windows(eng, canvas, out, tiles[sl], h_starts, w_starts, tile_size, accumulate=True)
         sample = blend_normalize(eng, canvas, 1.0)
     return (sample / sd)[None]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# Bounded twins of the decoder and coarse stages (training/evaluation/sample_diffusion_decoder.py:44-211, sample_coarse.py:29-125): the same
+# call surface as the reference functions, every tile of every batch item run through the engine in batches (tiles are independent), blended
+# with the engine's deterministic gather in the reference's loop order.
+def _cond_tiles(cond_img, h, w, device):
+    """cond_img -> (b, Cc, h, w) fp32 on the device, nearest-resized when its spatial size differs (sample_diffusion_decoder.py:82-84)."""
+    cond_img = torch.as_tensor(cond_img).to(device=device, dtype=torch.float32)
+    if tuple(cond_img.shape[-2:]) != (h, w):
+        cond_img = torch.nn.functional.interpolate(cond_img, size=(h, w), mode="nearest")
+    return cond_img.contiguous()
+
+
+def _blend_batch(eng, tiles, b, n_tiles, tile_idx, h_starts, w_starts, tile_size, h, w, scale):
+    """tiles (n_tiles*b, C, T, T) ordered tile-major, batch-minor -> (b, C, h, w): out / out_w of the reference loops, times `scale`."""
+    C_ = tiles.shape[1]
+    outs = []
+    for k in range(b):
+        canvas = torch.zeros((C_ + 1, h, w), dtype=torch.float32, device=tiles.device)
+        blend_windows(eng, canvas, tiles[k::b].contiguous(), tile_idx, h_starts, w_starts, tile_size, accumulate=False)
+        outs.append(blend_normalize(eng, canvas, scale))
+    return torch.stack(outs)
+
+
+def _tile_geometry(h, w, tile_size, tile_stride, default):
+    tile_size = default if tile_size is None else int(tile_size)
+    tile_stride = tile_size if tile_stride is None else int(tile_stride)
+    h_starts, w_starts = _tile_starts(h, tile_size, tile_stride), _tile_starts(w, tile_size, tile_stride)
+    tile_idx = [(ic, jc) for ic in range(len(h_starts)) for jc in range(len(w_starts))]
+    return tile_size, h_starts, w_starts, tile_idx
+
+
+@torch.no_grad()
+def sample_decoder_diffusion_tiled(model, scheduler, cond_img, noise, tile_size=None, tile_stride=None, *, num_steps=None, guidance_model=None,
+                                   guidance_scale=1.0, score_scaling=1.0, weight_window_fn=None, max_batch=64):
+    """sample_diffusion_decoder.py:44-125: tiled conditional EDM sampling of a decoder model.  `noise` is the initial sample as the caller
+    scaled it (the reference uses it as is), `cond_img` is concatenated after the sample channels.  Returns out / out_w (no sigma_data
+    division -- the reference has none here).  Not supported (raise): a guide model together with conditioning-image channels, score scaling
+    other than 1, custom weight windows."""
+    if weight_window_fn is not None or score_scaling != 1.0:
+        raise NotImplementedError("custom weight windows / score scaling")
+    if guidance_model is not None and guidance_scale != 1.0:
+        raise NotImplementedError("autoguidance with conditioning-image channels")
+    if num_steps is not None:
+        scheduler.set_timesteps(num_steps)
+    steps = len(scheduler.timesteps)
+    eng, dev = model.engine, model.device
+    noise = torch.as_tensor(noise).to(device=dev, dtype=torch.float32)
+    b, c, h, w = noise.shape
+    cond_img = _cond_tiles(cond_img, h, w, dev)
+    T, h_starts, w_starts, tile_idx = _tile_geometry(h, w, tile_size, tile_stride, min(h, w))
+    outs = []
+    jobs = [(i0, j0) for i0 in h_starts for j0 in w_starts]
+    per = max(1, max_batch // b)
+    for a in range(0, len(jobs), per):
+        chunk = jobs[a:a + per]
+        x = torch.cat([noise[:, :, i0:i0 + T, j0:j0 + T] for i0, j0 in chunk]).contiguous()       # tile-major, batch-minor
+        ci = torch.cat([cond_img[:, :, i0:i0 + T, j0:j0 + T] for i0, j0 in chunk]).contiguous()
+        outs.append(sample_tiles_edm(model, scheduler, x, None, steps, cond_img=ci))
+    return _blend_batch(eng, torch.cat(outs), b, len(jobs), tile_idx, h_starts, w_starts, T, h, w, 1.0)
+
+
+@torch.no_grad()
+def sample_decoder_consistency_tiled(model, scheduler, cond_img, noise, tile_size=None, tile_stride=None, *, intermediate_t=None, weight_window_fn=None,
+                                     max_batch=64):
+    """sample_diffusion_decoder.py:129-211: n-step trig-flow consistency sampling of a decoder model per tile (every step re-noises with the
+    SAME tile noise), blended, divided by sigma_data."""
+    if weight_window_fn is not None:
+        raise NotImplementedError("custom weight windows")
+    eng, dev = model.engine, model.device
+    noise = torch.as_tensor(noise).to(device=dev, dtype=torch.float32)
+    b, c, h, w = noise.shape
+    cond_img = _cond_tiles(cond_img, h, w, dev)
+    sd = float(scheduler.config.sigma_data)
+    init_t = float(torch.atan(torch.as_tensor(float(scheduler.sigmas[0]) / sd, dtype=torch.float32)))
+    if intermediate_t is None:
+        extra = []
+    elif torch.is_tensor(intermediate_t):
+        extra = [float(t) for t in intermediate_t.flatten().to(torch.float32)]
+    elif isinstance(intermediate_t, (list, tuple)):
+        extra = [float(torch.tensor(t, dtype=torch.float32)) for t in intermediate_t]
+    else:
+        extra = [float(torch.tensor(float(intermediate_t), dtype=torch.float32))]
+    T, h_starts, w_starts, tile_idx = _tile_geometry(h, w, tile_size, tile_stride, min(h, w))
+    jobs = [(i0, j0) for i0 in h_starts for j0 in w_starts]
+    per = max(1, max_batch // b)
+    outs = []
+    for a in range(0, len(jobs), per):
+        chunk = jobs[a:a + per]
+        z = torch.cat([noise[:, :, i0:i0 + T, j0:j0 + T] for i0, j0 in chunk]).contiguous()
+        ci = torch.cat([cond_img[:, :, i0:i0 + T, j0:j0 + T] for i0, j0 in chunk]).contiguous()
+        sample = None
+        for t in [init_t] + extra:
+            sample = consistency_step(model, t, sd, sample, z, cond=None, cond_img=ci)
+        outs.append(sample)
+    return _blend_batch(eng, torch.cat(outs), b, len(jobs), tile_idx, h_starts, w_starts, T, h, w, 1.0 / sd)
+
+
+@torch.no_grad()
+def sample_coarse_tiled(model, scheduler, cond_img, cond_snr, *, steps=15, tile_size=None, tile_stride=None, weight_window_fn=None, generator=None,
+                        dtype=torch.float32, cond_noise=None, init_noise=None, noise_seed=42, max_batch=64):
+    """sample_coarse.py:29-125: the coarse model on a bounded (b, C_cond, h, w) conditioning image.  The conditioning image is mixed with
+    noise at the per-channel SNR, every tile starts from sigma_0 * noise, runs `steps` DPM-Solver++ steps with the five log(tan(atan(snr)) / 8)
+    conditional scalars, is divided by sigma_data and blended.
+    The reference draws both noises from torch's generators (torch.randn_like / torch.randn), which nothing else can reproduce: pass
+    `cond_noise` (b, C_cond, h, w) and `init_noise` (list of (b, C_out, T, T), one per tile in row-major tile order) to pin them, otherwise
+    they come from the portable stream seeded `noise_seed` (+1 + tile index for the tiles)."""
+    if weight_window_fn is not None:
+        raise NotImplementedError("custom weight windows")
+    eng, dev = model.engine, model.device
+    cond_img = torch.as_tensor(cond_img).to(device=dev, dtype=torch.float32)
+    assert cond_img.ndim == 4, "cond_img must be [B, C, H, W]"
+    b, c_cond, h, w = cond_img.shape
+    T, h_starts, w_starts, tile_idx = _tile_geometry(h, w, tile_size, tile_stride, w)
+    c_out = int(model.config["out_channels"])
+    snr = torch.as_tensor(cond_snr, dtype=torch.float32)
+    t_cond = torch.atan(snr)
+    cond_vals = torch.log(torch.tan(t_cond) / 8.0)                                        # sample_coarse.py:7-26
+    cond_inputs = [v.reshape(-1) for v in cond_vals.reshape(-1, cond_vals.shape[-1]).transpose(0, 1)]
+    tc = t_cond.reshape(1, -1, 1, 1).to(dev)
+    if cond_noise is None:
+        cond_noise = torch.from_numpy(_noise.standard_normal(noise_seed, tuple(cond_img.shape)))
+    cond_img = (torch.cos(tc) * cond_img + torch.sin(tc) * torch.as_tensor(cond_noise).to(dev, torch.float32)).contiguous()
+    scheduler.set_timesteps(int(steps))
+    sd = float(scheduler.config.sigma_data)
+    sigma0 = float(scheduler.sigmas[0])
+    jobs = [(i0, j0) for i0 in h_starts for j0 in w_starts]
+    per = max(1, max_batch // b)
+    outs = []
+    for a in range(0, len(jobs), per):
+        chunk = list(enumerate(jobs))[a:a + per]
+        xs = []
+        for k, (i0, j0) in chunk:
+            z = init_noise[k] if init_noise is not None else torch.from_numpy(_noise.standard_normal(noise_seed + 1 + k, (b, c_out, T, T)))
+            xs.append(torch.as_tensor(z).to(dev, torch.float32) * sigma0)
+        x = torch.cat(xs).contiguous()
+        ci = torch.cat([cond_img[:, :, i0:i0 + T, j0:j0 + T] for _, (i0, j0) in chunk]).contiguous()
+        n = x.shape[0]
+        cond = model.cond_rows([v if v.numel() == 1 else v.repeat(len(chunk)) for v in cond_inputs], n, dev)   # tile-major, batch-minor rows
+        sample_tiles_edm(model, scheduler, x, cond, int(steps), cond_img=ci)
+        outs.append(x)
+    return _blend_batch(eng, torch.cat(outs), b, len(jobs), tile_idx, h_starts, w_starts, T, h, w, 1.0 / sd)

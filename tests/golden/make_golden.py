@@ -475,7 +475,54 @@ def gen_latent_glue():
     save("latent_glue", **out)
 
 
-ALL = dict(compose=gen_compose, guided=gen_guided, latent_glue=gen_latent_glue, stage_glue=gen_stage_glue, stages=gen_stages, rng=gen_rng, geometry=gen_geometry, schedule=gen_schedule, unet=gen_unet, sampling=gen_sampling)
+def gen_bounded_twins():
+    """The bounded decoder / coarse samplers (training/evaluation/sample_diffusion_decoder.py:44-211, sample_coarse.py:29-125) run from the
+    reference's own modules on full-size decoder / coarse architectures at small canvases.  The reference draws the coarse sampler's noises with
+    torch.randn / torch.randn_like; they are replaced by portable-RNG tensors (recorded by seed) so that any implementation can replay them."""
+    from terrain_diffusion.scheduler.dpmsolver import EDMDPMSolverMultistepScheduler
+    from terrain_diffusion.training.evaluation import sample_diffusion_decoder as sdd, sample_coarse as sc
+    from oracle import rng
+    from oracle.unet import COARSE_CONFIG, DECODER_CONFIG, synth_state_dict
+    out = {}
+    md = _ref_model(dict(DECODER_CONFIG), synth_state_dict(DECODER_CONFIG, seed=2468))
+    sch = EDMDPMSolverMultistepScheduler(sigma_min=0.002, sigma_max=80.0, sigma_data=0.5)
+    # decoder: batch of 2, canvas 40 x 56, tiles of 32 with stride 24 (ragged last tile), 4 conditioning channels
+    noise = torch.from_numpy(rng.standard_normal(901, (2, 1, 40, 56)))
+    cond = torch.from_numpy(rng.standard_normal(902, (2, 4, 40, 56)))
+    # (finding: the reference's decoder DIFFUSION sampler sets the timesteps once, outside its tile loop, so the scheduler's step index runs off
+    # the sigma table on the second tile -- IndexError at dpmsolver.py:512.  It only works for one tile; the goldens are single-tile.)
+    sq = torch.from_numpy(rng.standard_normal(908, (2, 1, 40, 40)))
+    csq = torch.from_numpy(rng.standard_normal(909, (2, 4, 40, 40)))
+    out["dec_diffusion_b2_40x40_steps6"] = sdd.sample_decoder_diffusion_tiled(md, sch, csq, sq * 80.0, num_steps=6).numpy()
+    # conditioning image at half resolution (nearest upsampling inside the sampler), one tile = whole canvas
+    cond_lo = torch.from_numpy(rng.standard_normal(903, (2, 4, 16, 16)))
+    noise32 = torch.from_numpy(rng.standard_normal(904, (2, 1, 32, 32)))
+    out["dec_diffusion_b2_32x32_condlo_steps4"] = sdd.sample_decoder_diffusion_tiled(md, sch, cond_lo, noise32 * 80.0, num_steps=4).numpy()
+    sch.set_timesteps(20)
+    out["dec_consistency_b2_40x56_t32_s24_1step"] = sdd.sample_decoder_consistency_tiled(md, sch, cond, noise, 32, 24).numpy()
+    out["dec_consistency_b2_40x56_t32_s24_3step"] = sdd.sample_decoder_consistency_tiled(md, sch, cond, noise, 32, 24, intermediate_t=[float(np.arctan(0.35 / 0.5)), 0.2]).numpy()
+    # coarse: 5 conditioning channels at 64 x 64, ONE tile (the same step-index bug as above makes a second tile fail), 5 steps; noises pinned
+    mc = _ref_model(dict(COARSE_CONFIG), synth_state_dict(COARSE_CONFIG, seed=4321))
+    cimg = torch.from_numpy(rng.standard_normal(905, (1, 5, 64, 64)))
+    snr = torch.tensor([[0.5, 0.4, 0.6, 0.3, 0.8]])
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+    calls = []
+
+    def fake_randn(*shape, generator=None, device=None, dtype=None, **kw):
+        shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+        calls.append(shape)
+        return torch.from_numpy(rng.standard_normal(907 + len(calls) - 1, shape))
+    torch.randn = fake_randn
+    torch.randn_like = lambda t, **kw: torch.from_numpy(rng.standard_normal(906, tuple(t.shape)))
+    try:
+        out["coarse_64x64_steps5"] = sc.sample_coarse_tiled(mc, sch, cimg, snr, steps=5).numpy()
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_randn_like
+    assert calls == [(1, 6, 64, 64)], calls
+    save("bounded_twins", **out)
+
+
+ALL = dict(bounded_twins=gen_bounded_twins, compose=gen_compose, guided=gen_guided, latent_glue=gen_latent_glue, stage_glue=gen_stage_glue, stages=gen_stages, rng=gen_rng, geometry=gen_geometry, schedule=gen_schedule, unet=gen_unet, sampling=gen_sampling)
 
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden generation needs the reference checkout"

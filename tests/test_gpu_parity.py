@@ -752,3 +752,57 @@ def test_output_composition_elev_and_climate_vs_oracle(td, orc):
     got = cp.compute_climate(coarse, i1, j1, i2, j2, elev.cuda(), 8)
     assert got.shape == ref.shape == (5, 512, 660)
     assert rel_rms(got.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+def test_bounded_decoder_and_coarse_twins_vs_reference(td, golden, orc):
+    """SURVEY.md §2 ★ components: sample_decoder_diffusion_tiled / sample_decoder_consistency_tiled /
+    sample_coarse_tiled (training/evaluation/sample_diffusion_decoder.py:44-211, sample_coarse.py:29-125) on the engine, against outputs of
+    the reference functions themselves (tests/golden/bounded_twins.npz, fp32 engine mode, tolerance 1e-5 rel-RMS).
+    Finding while generating the fixtures: the reference's decoder-diffusion and coarse samplers set the scheduler's timesteps once, outside
+    their tile loops, so the step index runs off the sigma table on the second tile (IndexError, dpmsolver.py:512); only their single-tile
+    form runs.  The consistency sampler is fine with many tiles.  The engine twins run any number of tiles; the multi-tile diffusion case is
+    checked against a manual blend of single-tile runs."""
+    from oracle import rng, tiling
+    U = orc["unet"]
+    g = golden("bounded_twins")
+    md = td.EDMUnet2D(**U.DECODER_CONFIG, dtype="fp32").load_state_dict(U.synth_state_dict(U.DECODER_CONFIG, seed=2468))
+    sch = td.EDMDPMSolverMultistepScheduler(sigma_min=0.002, sigma_max=80.0, sigma_data=0.5)
+    noise = torch.from_numpy(rng.standard_normal(901, (2, 1, 40, 56)))
+    cond = torch.from_numpy(rng.standard_normal(902, (2, 4, 40, 56)))
+    sq = torch.from_numpy(rng.standard_normal(908, (2, 1, 40, 40)))
+    csq = torch.from_numpy(rng.standard_normal(909, (2, 4, 40, 40)))
+    got = td.sample_decoder_diffusion_tiled(md, sch, csq, sq * 80.0, num_steps=6)
+    assert rel_rms(got.cpu().numpy(), g["dec_diffusion_b2_40x40_steps6"]) < 1e-5
+    cond_lo = torch.from_numpy(rng.standard_normal(903, (2, 4, 16, 16)))
+    noise32 = torch.from_numpy(rng.standard_normal(904, (2, 1, 32, 32)))
+    got = td.sample_decoder_diffusion_tiled(md, sch, cond_lo, noise32 * 80.0, num_steps=4)
+    assert rel_rms(got.cpu().numpy(), g["dec_diffusion_b2_32x32_condlo_steps4"]) < 1e-5
+    sch.set_timesteps(20)
+    got = td.sample_decoder_consistency_tiled(md, sch, cond, noise, 32, 24)
+    assert rel_rms(got.cpu().numpy(), g["dec_consistency_b2_40x56_t32_s24_1step"]) < 1e-5
+    got = td.sample_decoder_consistency_tiled(md, sch, cond, noise, 32, 24, intermediate_t=[float(np.arctan(0.35 / 0.5)), 0.2])
+    assert rel_rms(got.cpu().numpy(), g["dec_consistency_b2_40x56_t32_s24_3step"]) < 1e-5
+    # multi-tile diffusion (the reference cannot run it): equals the blend of the same tiles sampled one canvas at a time
+    multi = td.sample_decoder_diffusion_tiled(md, sch, cond, noise * 80.0, 32, 24, num_steps=5).cpu()
+    w = tiling.linear_weight_window(32)
+    acc, wsum = torch.zeros(2, 1, 40, 56), torch.zeros(40, 56)
+    for i0 in tiling.tile_starts(40, 32, 24):
+        for j0 in tiling.tile_starts(56, 32, 24):
+            one = td.sample_decoder_diffusion_tiled(md, sch, cond[..., i0:i0 + 32, j0:j0 + 32], noise[..., i0:i0 + 32, j0:j0 + 32] * 80.0, num_steps=5).cpu()
+            acc[..., i0:i0 + 32, j0:j0 + 32] += one * w
+            wsum[i0:i0 + 32, j0:j0 + 32] += w
+    assert rel_rms(multi.numpy(), (acc / wsum).numpy()) < 1e-6
+    md.close()
+    # coarse twin, noises pinned to what the fixture generator fed the reference
+    mc = td.EDMUnet2D(**U.COARSE_CONFIG, dtype="fp32").load_state_dict(U.synth_state_dict(U.COARSE_CONFIG, seed=4321))
+    cimg = torch.from_numpy(rng.standard_normal(905, (1, 5, 64, 64)))
+    snr = torch.tensor([[0.5, 0.4, 0.6, 0.3, 0.8]])
+    got = td.sample_coarse_tiled(mc, sch, cimg, snr, steps=5, cond_noise=torch.from_numpy(rng.standard_normal(906, (1, 5, 64, 64))),
+                                 init_noise=[torch.from_numpy(rng.standard_normal(907, (1, 6, 64, 64)))])
+    assert rel_rms(got.cpu().numpy(), g["coarse_64x64_steps5"]) < 1e-5
+    # two tiles, portable default noises: finite, deterministic, and the first tile's private corner equals the single-tile run on that crop
+    big = torch.from_numpy(rng.standard_normal(910, (1, 5, 112, 64)))
+    a = td.sample_coarse_tiled(mc, sch, big, snr, steps=5, tile_size=64, tile_stride=48, noise_seed=5)
+    b = td.sample_coarse_tiled(mc, sch, big, snr, steps=5, tile_size=64, tile_stride=48, noise_seed=5)
+    assert a.shape == (1, 6, 112, 64) and torch.isfinite(a).all() and torch.equal(a, b)
+    mc.close()

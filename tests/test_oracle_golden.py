@@ -284,3 +284,32 @@ def test_autoguidance_oracle_matches_reference(golden):
         cond = tiling.synthetic_cond_grid(len(tiling.tile_starts(H, 16, 8)), len(tiling.tile_starts(W, 16, 8)))
         y = tiling.sample_base_diffusion_tiled(m, (1, 5, H, W), cond, steps=steps, tile_size=16, guide_model=gm, guidance_scale=scale)
         assert rel_rms(y.numpy(), g[key]) < 1e-5, key
+
+
+def test_oracle_bounded_decoder_and_coarse_samplers_vs_reference():
+    """oracle/tiling.py's restatements of sample_decoder_diffusion_tiled / sample_decoder_consistency_tiled / sample_coarse_tiled against the
+    outputs of the reference functions (tests/golden/bounded_twins.npz, generated by make_golden.py gen_bounded_twins)."""
+    import numpy as np
+    import torch
+    from oracle import rng, tiling
+    from oracle.unet import COARSE_CONFIG, DECODER_CONFIG, OracleUnet, synth_state_dict
+    from conftest import rel_rms, GOLDEN
+    import os
+    g = np.load(os.path.join(GOLDEN, "bounded_twins.npz"))
+    od = OracleUnet(DECODER_CONFIG, synth_state_dict(DECODER_CONFIG, seed=2468))
+    noise = torch.from_numpy(rng.standard_normal(901, (2, 1, 40, 56)))
+    cond = torch.from_numpy(rng.standard_normal(902, (2, 4, 40, 56)))
+    sq = torch.from_numpy(rng.standard_normal(908, (2, 1, 40, 40)))
+    csq = torch.from_numpy(rng.standard_normal(909, (2, 4, 40, 40)))
+    assert rel_rms(tiling.sample_decoder_diffusion_tiled(od, csq, sq * 80.0, num_steps=6).numpy(), g["dec_diffusion_b2_40x40_steps6"]) < 1e-5
+    cond_lo = torch.from_numpy(rng.standard_normal(903, (2, 4, 16, 16)))
+    noise32 = torch.from_numpy(rng.standard_normal(904, (2, 1, 32, 32)))
+    assert rel_rms(tiling.sample_decoder_diffusion_tiled(od, cond_lo, noise32 * 80.0, num_steps=4).numpy(), g["dec_diffusion_b2_32x32_condlo_steps4"]) < 1e-5
+    assert rel_rms(tiling.sample_decoder_consistency_tiled(od, cond, noise, 32, 24).numpy(), g["dec_consistency_b2_40x56_t32_s24_1step"]) < 1e-5
+    assert rel_rms(tiling.sample_decoder_consistency_tiled(od, cond, noise, 32, 24, intermediate_t=[float(np.arctan(0.35 / 0.5)), 0.2]).numpy(),
+                   g["dec_consistency_b2_40x56_t32_s24_3step"]) < 1e-5
+    oc = OracleUnet(COARSE_CONFIG, synth_state_dict(COARSE_CONFIG, seed=4321))
+    cimg = torch.from_numpy(rng.standard_normal(905, (1, 5, 64, 64)))
+    got = tiling.sample_coarse_tiled(oc, cimg, torch.tensor([[0.5, 0.4, 0.6, 0.3, 0.8]]), steps=5, cond_noise=torch.from_numpy(rng.standard_normal(906, (1, 5, 64, 64))),
+                                     init_noise=[torch.from_numpy(rng.standard_normal(907, (1, 6, 64, 64)))])
+    assert rel_rms(got.numpy(), g["coarse_64x64_steps5"]) < 1e-5
