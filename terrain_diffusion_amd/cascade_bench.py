@@ -29,16 +29,23 @@ def run_cascade(args, eng, dev, rank, world):
     for cfg, seed in ((COARSE_CONFIG, 11), (BASE_CONFIG, 1234), (DECODER_CONFIG, 2468)):
         m = td.EDMUnet2D(**cfg, dtype=dtype, device=dev)
         models.append(m.load_state_dict(synthetic_state_dict(m, seed=seed)))
-    R, Q = 3072, 1024                       # region and request size in decoded pixels (3 x 3 requests per step)
+    # region and request size in decoded pixels.  N = 1: 3 x 3 requests per step (the round-2 workload).  N > 1: ONE 6 x 6-request region of ONE
+    # world (same seed on every rank) whose requests are dealt to the ranks in spatially compact shares (parallel.shard_requests: Z-curve order, so
+    # a rank's decoder windows share latent / coarse windows); every rank holds the whole lazy graph, no window crosses a GPU boundary and there
+    # is no data-path collective ("request-replica" mode).  Total work is fixed -> strong scaling; the N = 1 point of that workload is
+    # `python bench.py --workload cascade --region 6144`.
+    R, Q = (int(getattr(args, "region", 0)) or (3072 if world == 1 else 6144)), 1024
+    from terrain_diffusion_amd.parallel import shard_requests
     cache = int(getattr(args, 'cache_mib', 100)) * 2 ** 20   # default 100 MiB = the reference's cache_limit (world_pipeline.py:311); one step produces ~150 MiB of windows -> streaming eviction
-    world_p = td.WorldPipeline.from_models(*models, seed=4242 + rank, dtype=dtype, device=dev, cache_limit=cache, latents_batch_size=(1, 2, 4, 8, 16, 32, 64)).bind()
+    world_p = td.WorldPipeline.from_models(*models, seed=4242, dtype=dtype, device=dev, cache_limit=cache, latents_batch_size=(1, 2, 4, 8, 16, 32, 64)).bind()
 
     def one_step(i):
         i0, j0 = 100_000 * (i + 1), -50_000 * (i + 1)
         out = None
-        for a in range(0, R, Q):
-            for b in range(0, R, Q):
-                out = world_p.get(i0 + a, j0 + b, i0 + a + Q, j0 + b + Q)
+        boxes = [(i0 + a, j0 + b, i0 + a + Q, j0 + b + Q) for a in range(0, R, Q) for b in range(0, R, Q)]
+        mine = [bx for _, bx in shard_requests(boxes, world, rank)] if world > 1 else boxes
+        for bx in mine:
+            out = world_p.get(*bx)
         return out
 
     def sync():
@@ -54,8 +61,15 @@ def run_cascade(args, eng, dev, rank, world):
     for i in range(args.steps):
         out = one_step(i)
     sync()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     dt = time.perf_counter() - t0
-    assert bool(torch.isfinite(out["elev"]).all())
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert out is None or bool(torch.isfinite(out["elev"]).all())
     mp = R * R / 1e6
     value = args.steps * mp / dt
     # per-stage kernel time: one profiled (eager) request of fresh terrain
@@ -79,12 +93,12 @@ def run_cascade(args, eng, dev, rank, world):
     tflops = value * GFLOP_PER_MP / 1e3
     result = {
         "metric": "terrain megapixels/sec (decoded) at fixed steps, 30m model", "value": round(value, 4), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": args.dtype,
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[4] shapes on one GPU: coarse -> 2-phase latent -> decoder (512x512 / stride 384) cascade through the lazy device-resident "
                                f"graph + elevation/climate composition, {R}x{R} decoded pixels per step in {Q}x{Q} requests, window cache capped at {cache >> 20} MiB "
                                "(streaming eviction)",
-                   "decoded_mp_per_step": mp, "windows_per_step": {k: round(t.windows_computed / args.steps, 1) for k, t in
+                   "decoded_mp_per_step": mp, "parallelism": (f"{world} ranks, request-replica mode: one world, requests dealt in Z-curve order, no data-path collective" if world > 1 else "1 rank"), "windows_per_step": {k: round(t.windows_computed / args.steps, 1) for k, t in
                                                                    (("coarse", world_p.coarse), ("latent_final_phase", world_p.latents), ("decoder", world_p.residual))},
                    "cache_evictions_per_step": round((world_p.tile_store.evictions - ev0) / args.steps, 1)},
         "roofline": {"bound": "mfma", "kernel": "td::conv_glds_kernel (all stages)", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "achieved": round(tflops, 2),

@@ -47,8 +47,12 @@ def _cuts(n, parts):
 class ShardPlan:
     """Static description of who samples which window, who owns which canvas region and which window outputs cross seams."""
 
-    def __init__(self, H, W, tile_size, world, stride=None):
+    def __init__(self, H, W, tile_size, world, stride=None, extended=False):
+        """extended=False: a rank's region is the canvas area it OWNS (the regions tile the canvas).  extended=True: the region is the bounding
+        box of the rank's own windows -- what it needs of an intermediate phase's blended canvas to cut the next phase's window inputs from
+        (multi-phase samplers); extended regions overlap, and `needed` / `sends` grow by the windows that reach into the wider box."""
         self.H, self.W, self.size, self.world = H, W, tile_size, world
+        self.extended = bool(extended)
         stride = stride or tile_size // 2
         self.h_starts, self.w_starts = _tile_starts(H, tile_size, stride), _tile_starts(W, tile_size, stride)
         nr, nc = len(self.h_starts), len(self.w_starts)
@@ -71,7 +75,11 @@ class ShardPlan:
                 y1 = self.h_starts[self.row_cuts[br + 1]] if br + 1 < self.pr else H
                 x0 = self.w_starts[self.col_cuts[bc]] if bc > 0 else 0
                 x1 = self.w_starts[self.col_cuts[bc + 1]] if bc + 1 < self.pc else W
-                self.regions.append((y0, y1, x0, x1))
+                if extended:
+                    y1 = self.h_starts[self.row_cuts[br + 1] - 1] + tile_size
+                    x1 = self.w_starts[self.col_cuts[bc + 1] - 1] + tile_size
+                    y0, x0 = self.h_starts[self.row_cuts[br]], self.w_starts[self.col_cuts[bc]]
+                self.regions.append((y0, min(y1, H), x0, min(x1, W)))
         # windows intersecting each region, and the seam traffic (src -> dst: windows of src that dst's region needs)
         self.needed = []
         for r, (y0, y1, x0, x1) in enumerate(self.regions):
@@ -203,3 +211,110 @@ def sample_base_diffusion_sharded(model, scheduler, shape, cond_inputs, *, cond_
         return full[None]
     dist.send(region.contiguous(), gather_to, group)
     return None
+
+
+def consistency_engine_fns(model, plan, cond_inputs, *, cond_means, cond_stds, noise_level, histogram_raw, channels, noise_seed, noise_origin, max_batch, sigma_data):
+    """(step_fn, blend_fn, normalize_fn) backed by the HIP engine for the multi-phase sampler: step_fn(windows, k, t, prev_tiles) runs ONE
+    trig-flow consistency step (world_pipeline.py:1097-1129) on the given windows; prev_tiles is None in the first phase."""
+    from . import sampling as _s
+    from . import noise as _noise
+    from ._lib import lib, check
+    from .engine import ptr
+    dev = model.device
+
+    def step_fn(windows, k, t, prev_tiles):
+        cond = torch.as_tensor(cond_inputs, dtype=torch.float32)
+        outs = []
+        for b0 in range(0, len(windows), max_batch):
+            chunk = windows[b0:b0 + max_batch]
+            origins = [(noise_origin[0] + plan.h_starts[ic], noise_origin[1] + plan.w_starts[jc]) for ic, jc in chunk]
+            z = _noise.gaussian_noise_patches(noise_seed + k, origins, plan.size, plan.size, channels=channels, tile_h=64, tile_w=64, device=dev)
+            c58 = _s._tile_conditioning(cond, chunk, histogram_raw, cond_means, cond_stds, noise_level).to(dev).contiguous()
+            prev = None if prev_tiles is None else prev_tiles[b0:b0 + max_batch].contiguous()
+            out = torch.empty_like(z)
+            check(lib().td_sample_consistency(model._h, z.shape[0], plan.size, plan.size, float(t), float(sigma_data), ptr(prev), ptr(z), ptr(c58), ptr(out)))
+            outs.append(out)
+        return torch.cat(outs)
+
+    def blend_fn(canvas, tiles, wins, hs, ws, size):
+        _s.blend_windows(model.engine, canvas, tiles, wins, hs, ws, size, accumulate=False)
+
+    def normalize_fn(canvas, scale):
+        return _s.blend_normalize(model.engine, canvas, scale)
+
+    return step_fn, blend_fn, normalize_fn
+
+
+def sample_base_consistency_sharded(model, scheduler, shape, cond_inputs, *, cond_means, cond_stds, noise_level=0.0, histogram_raw, intermediate_t=0.0,
+                                    tile_size=64, noise_seed=42 + 5819, noise_origin=(0, 0), max_batch=64, group=None, gather_to=None,
+                                    step_fn=None, blend_fn=None, normalize_fn=None, stats=None):
+    """Sharded sample_base_consistency (sample_diffusion_base.py:171-268; the latent stage's blended trig-flow phases, world_pipeline.py:1133-1203).
+    T phases = T seam exchanges: in every phase a rank runs one consistency step on ITS windows, then receives the outputs of the
+    neighbours' windows it needs and blends
+      * after an intermediate phase: the bounding box of its own windows (ShardPlan(extended=True)) -- the next phase cuts every window's input
+        sample out of that box, so no blended canvas ever crosses a seam, only window outputs do (canonical per-pixel summation order);
+      * after the last phase: the region it owns.
+    In batch-invariant engine mode the assembled canvas is bit-identical to the one-rank sampler.  Returns like sample_base_diffusion_sharded."""
+    B, C_, H, W = shape
+    assert B == 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    own, ext = ShardPlan(H, W, tile_size, world), ShardPlan(H, W, tile_size, world, extended=True)
+    sd = float(scheduler.config.sigma_data)
+    t0 = float(torch.atan(torch.tensor(float(scheduler.config.sigma_max), dtype=torch.float32) / sd))
+    t_scalars = (t0, float(torch.tensor(intermediate_t, dtype=torch.float32))) if intermediate_t > 0 else (t0,)
+    if step_fn is None:
+        step_fn, blend_fn, normalize_fn = consistency_engine_fns(model, own, cond_inputs, cond_means=cond_means, cond_stds=cond_stds, noise_level=noise_level,
+                                                                 histogram_raw=histogram_raw, channels=C_, noise_seed=noise_seed, noise_origin=noise_origin,
+                                                                 max_batch=max_batch, sigma_data=sd)
+    mine = own.windows[rank]
+    prev_tiles, region = None, None
+    for k, t in enumerate(t_scalars):
+        last = k == len(t_scalars) - 1
+        plan = own if last else ext
+        out = step_fn(mine, k, t, prev_tiles)
+        have = exchange_windows(plan, rank, out, group) if world > 1 else {w: out[i] for i, w in enumerate(mine)}
+        if stats is not None:
+            stats["exchanges"] = stats.get("exchanges", 0) + (1 if world > 1 else 0)
+            stats["seam_bytes_total"] = stats.get("seam_bytes_total", 0) + sum(plan.seam_bytes(C_).values())
+        region = blend_region(plan, rank, have, blend_fn, normalize_fn, C_, (1.0 / sd) if last else 1.0)
+        if not last:   # next phase's window inputs, cut from this rank's own blended box
+            y0, _, x0, _ = ext.regions[rank]
+            prev_tiles = torch.stack([region[:, own.h_starts[ic] - y0:own.h_starts[ic] - y0 + tile_size, own.w_starts[jc] - x0:own.w_starts[jc] - x0 + tile_size]
+                                      for ic, jc in mine]).contiguous()
+    if gather_to is None:
+        return region, own.regions[rank]
+    if world == 1:
+        return region[None]
+    if rank == gather_to:
+        full = torch.empty((C_, H, W), dtype=torch.float32, device=region.device)
+        for r, (y0, y1, x0, x1) in enumerate(own.regions):
+            if r == rank:
+                full[:, y0:y1, x0:x1] = region
+            else:
+                buf = torch.empty((C_, y1 - y0, x1 - x0), dtype=torch.float32, device=region.device)
+                dist.recv(buf, r, group)
+                full[:, y0:y1, x0:x1] = buf
+        return full[None]
+    dist.send(region.contiguous(), gather_to, group)
+    return None
+
+
+def shard_requests(boxes, world=None, rank=None):
+    """Request-replica mode for WorldPipeline / the cascade on a multi-GPU node (BASELINE configs[4]): every rank holds the whole lazy graph
+    (weights are small, windows are recomputed where needed) and serves a contiguous, spatially compact share of the request boxes.  Boxes are
+    ordered along a Z-curve of their centres first, so that a rank's requests share upstream coarse / latent windows (the cascade's cost is
+    dominated by the latent stage: neighbouring decoder windows reuse it) and no window ever has to cross a GPU boundary -- the cascade needs no
+    data-path collective.  Returns the list of (index, box) this rank serves; the union over ranks is every box exactly once."""
+    world = (dist.get_world_size() if dist.is_initialized() else 1) if world is None else world
+    rank = (dist.get_rank() if dist.is_initialized() else 0) if rank is None else rank
+
+    def z(ci, cj):
+        ci, cj = int(ci) + (1 << 30), int(cj) + (1 << 30)
+        v = 0
+        for b in range(31):
+            v |= ((ci >> b) & 1) << (2 * b + 1) | ((cj >> b) & 1) << (2 * b)
+        return v
+    order = sorted(range(len(boxes)), key=lambda k: z((boxes[k][0] + boxes[k][2]) // 2, (boxes[k][1] + boxes[k][3]) // 2))
+    lo, hi = (rank * len(order)) // world, ((rank + 1) * len(order)) // world
+    return [(k, boxes[k]) for k in order[lo:hi]]

@@ -806,3 +806,48 @@ def test_bounded_decoder_and_coarse_twins_vs_reference(td, golden, orc):
     b = td.sample_coarse_tiled(mc, sch, big, snr, steps=5, tile_size=64, tile_stride=48, noise_seed=5)
     assert a.shape == (1, 6, 112, 64) and torch.isfinite(a).all() and torch.equal(a, b)
     mc.close()
+
+
+def test_sharded_two_phase_consistency_on_engine(td, orc):
+    """The multi-phase sharded sampler (parallel.sample_base_consistency_sharded: one window exchange per trig-flow phase, the next phase cut from
+    each rank's own blended box) on the ENGINE: one rank == td.sample_base_consistency, and two ranks simulated in memory (same plans, seam lists
+    and regional blends as the RCCL path) assemble the same canvas -- bit for bit in batch-invariant mode."""
+    from terrain_diffusion_amd.engine import get_engine
+    from terrain_diffusion_amd.parallel import ShardPlan, consistency_engine_fns, blend_region, sample_base_consistency_sharded
+    from oracle import tiling
+    eng = get_engine("cuda")
+    eng.set_option("batch_invariant", 1)
+    try:
+        cfg = orc["unet"].tiny_config(64, 1)
+        m = _model(td, orc, cfg, 77, "bf16")
+        sch = td.EDMDPMSolverMultistepScheduler()
+        H, W, S = 40, 56, 16
+        cond = tiling.synthetic_cond_grid(len(tiling.tile_starts(H, S, S // 2)), len(tiling.tile_starts(W, S, S // 2)))
+        kw = dict(cond_means=torch.zeros(7), cond_stds=torch.ones(7), noise_level=torch.tensor(0.0), histogram_raw=torch.zeros(1, 5))
+        it = float(np.arctan(0.35 / 0.5))
+        ref = td.sample_base_consistency(m, sch, (1, 5, H, W), cond, intermediate_t=it, tile_size=S, noise_seed=7, **kw)
+        one = sample_base_consistency_sharded(m, sch, (1, 5, H, W), cond, intermediate_t=it, tile_size=S, noise_seed=7, gather_to=0, **kw)
+        assert torch.equal(one, ref)
+        for world in (2, 4):
+            own, ext = ShardPlan(H, W, S, world), ShardPlan(H, W, S, world, extended=True)
+            step_fn, blend_fn, norm_fn = consistency_engine_fns(m, own, cond, channels=5, noise_seed=7, noise_origin=(0, 0), max_batch=64, sigma_data=0.5, **kw)
+            ts = (float(torch.atan(torch.tensor(80.0) / 0.5)), float(torch.tensor(it, dtype=torch.float32)))
+            prev = [None] * world
+            full = torch.empty((5, H, W), device="cuda")
+            for k, t in enumerate(ts):
+                last = k == len(ts) - 1
+                plan = own if last else ext
+                outs = [step_fn(own.windows[r], k, t, prev[r]) for r in range(world)]
+                for r in range(world):
+                    have = {w_: outs[plan.owner[w_]][own.windows[plan.owner[w_]].index(w_)] for w_ in plan.needed[r]}
+                    region = blend_region(plan, r, have, blend_fn, norm_fn, 5, 2.0 if last else 1.0)
+                    y0, y1, x0, x1 = plan.regions[r]
+                    if last:
+                        full[:, y0:y1, x0:x1] = region
+                    else:
+                        prev[r] = torch.stack([region[:, own.h_starts[ic] - y0:own.h_starts[ic] - y0 + S, own.w_starts[jc] - x0:own.w_starts[jc] - x0 + S]
+                                               for ic, jc in own.windows[r]]).contiguous()
+            assert torch.equal(full[None], ref), world
+        m.close()
+    finally:
+        eng.set_option("batch_invariant", 0)

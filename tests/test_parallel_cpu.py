@@ -114,3 +114,88 @@ def test_sharded_blend_bit_identical_gloo(world, H, W, S):
     ref = _reference_canvas(H, W, S).numpy()
     assert full.shape == (1, 5, H, W)
     assert np.array_equal(full[0], ref)
+
+
+# ---- multi-phase (consistency) sampler: one seam exchange per phase, intermediate phases blend the bounding box of a rank's own windows --------
+def _phase_tile(ic, jc, k, prev, S=16):
+    """CPU stand-in of one consistency step: depends on the window, the phase and (phases > 0) the previous phase's blended input."""
+    z = torch.from_numpy(rng.standard_normal(5000 + 997 * k + 37 * ic + jc, (5, S, S)))
+    return z * 0.5 if prev is None else torch.cos(prev) * 0.75 + z * 0.25
+
+
+def _reference_two_phase(H, W, S, n_phases):
+    hs, ws = tiling.tile_starts(H, S, S // 2), tiling.tile_starts(W, S, S // 2)
+    wins = [(ic, jc) for ic in range(len(hs)) for jc in range(len(ws))]
+    sample = None
+    for k in range(n_phases):
+        tiles = [_phase_tile(ic, jc, k, None if sample is None else sample[:, hs[ic]:hs[ic] + S, ws[jc]:ws[jc] + S], S) for ic, jc in wins]
+        canvas = torch.zeros(6, H, W)
+        _cpu_blend(canvas, tiles, wins, hs, ws, S)
+        sample = _cpu_norm(canvas, 1.0 if k < n_phases - 1 else 1.0 / 0.5)
+    return sample
+
+
+class _Sch2:
+    class config:
+        sigma_data = 0.5
+        sigma_max = 80.0
+
+
+def _worker_phases(rank, world, port, H, W, S, q):
+    from terrain_diffusion_amd.parallel import sample_base_consistency_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        stats = {}
+        plan = ShardPlan(H, W, S, world)
+        mine = plan.windows[rank]
+        step = lambda wins, k, t, prev: torch.stack([_phase_tile(ic, jc, k, None if prev is None else prev[i], S) for i, (ic, jc) in enumerate(wins)])
+        full = sample_base_consistency_sharded(None, _Sch2, (1, 5, H, W), None, cond_means=None, cond_stds=None, histogram_raw=None, intermediate_t=0.61, tile_size=S,
+                                               gather_to=0, step_fn=step, blend_fn=_cpu_blend, normalize_fn=_cpu_norm, stats=stats)
+        if rank == 0:
+            q.put((full.numpy(), stats))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H,W,S", [(2, 72, 72, 16), (4, 72, 104, 16), (2, 40, 24, 16)])
+def test_sharded_two_phase_consistency_bit_identical_gloo(world, H, W, S):
+    """the 2-phase latent stage sharded over ranks -- an exchange of window outputs per phase, the next phase's inputs
+    cut from each rank's own blended box -- is BIT-identical to the one-process loop (sample_diffusion_base.py:171-268 order)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_phases, args=(r, world, port, H, W, S, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, stats = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _reference_two_phase(H, W, S, 2).numpy()
+    assert full.shape == (1, 5, H, W) and np.array_equal(full[0], ref)
+    assert stats["exchanges"] == 2                                            # T phases = T exchanges (SURVEY.md 8e)
+    ext, own = ShardPlan(H, W, S, world, extended=True), ShardPlan(H, W, S, world)
+    assert stats["seam_bytes_total"] == sum(ext.seam_bytes().values()) + sum(own.seam_bytes().values())
+
+
+def test_extended_plan_and_request_sharding():
+    from terrain_diffusion_amd.parallel import shard_requests
+    for (H, W, size, world) in [(288, 288, 64, 2), (1056, 1056, 64, 8), (100, 230, 64, 4)]:
+        e = ShardPlan(H, W, size, world, extended=True)
+        for r, (y0, y1, x0, x1) in enumerate(e.regions):
+            for ic, jc in e.windows[r]:                                      # every own window lies inside the rank's box
+                assert y0 <= e.h_starts[ic] and e.h_starts[ic] + size <= y1 and x0 <= e.w_starts[jc] and e.w_starts[jc] + size <= x1
+            for ic, hs in enumerate(e.h_starts):                             # needed = every window that touches the box
+                for jc, ws in enumerate(e.w_starts):
+                    assert ((ic, jc) in e.needed[r]) == (hs < y1 and hs + size > y0 and ws < x1 and ws + size > x0)
+    boxes = [(1024 * a, 1024 * b, 1024 * a + 1024, 1024 * b + 1024) for a in range(-3, 5) for b in range(6)]
+    seen = []
+    for r in range(8):
+        part = shard_requests(boxes, world=8, rank=r)
+        assert len(part) == 6                                                # 48 boxes over 8 ranks
+        seen += [k for k, _ in part]
+        ys = [b[0] for _, b in part]; xs = [b[1] for _, b in part]
+        assert (max(ys) - min(ys)) * (max(xs) - min(xs)) <= 4 * 1024 * 4 * 1024   # a rank's share is spatially compact (Z-curve order)
+    assert sorted(seen) == list(range(len(boxes)))

@@ -198,3 +198,30 @@ def test_save_pretrained_round_trip(td, models, tmp_path):
     for m in (w2.coarse_model, w2.base_model, w2.decoder_model):
         m.close()
     w.close()
+
+
+def test_request_replica_mode_two_ranks_serve_the_same_world(td, models):
+    """BASELINE configs[4] on several GPUs: every rank holds the whole lazy graph of ONE world (same seed) and serves a
+    spatially compact share of the request boxes (parallel.shard_requests); no window crosses a GPU boundary.  Two 'ranks' (two pipelines on this
+    GPU) must return exactly what one pipeline returns for the same boxes -- bit for bit in batch-invariant mode, where a window's value does
+    not depend on the batch it was computed in."""
+    from terrain_diffusion_amd.engine import get_engine
+    from terrain_diffusion_amd.parallel import shard_requests
+    eng = get_engine("cuda")
+    eng.set_option("batch_invariant", 1)
+    try:
+        boxes = [(64 * a - 40, 64 * b + 8, 64 * a + 24, 64 * b + 72) for a in range(3) for b in range(2)]
+        one = _world(td, models)
+        ref = [one.get(*bx, with_climate=False)["elev"].clone() for bx in boxes]
+        one.close()
+        got = {}
+        for r in range(2):
+            w = _world(td, models)
+            for k, bx in shard_requests(boxes, world=2, rank=r):
+                got[k] = w.get(*bx, with_climate=False)["elev"].clone()
+            w.close()
+        assert sorted(got) == list(range(len(boxes)))
+        for k in range(len(boxes)):
+            assert torch.equal(got[k], ref[k]), k
+    finally:
+        eng.set_option("batch_invariant", 0)
