@@ -29,7 +29,7 @@ struct AttnStrides { long b, h, t, c; };  // element strides of (batch, head, to
 // grid (ceil(L / 64), H, B) x 3 roles via blockIdx.x ranges is overkill: one launch per operand (which = 0 q, 1 k, 2 v)
 template <typename TIN>
 __global__ __launch_bounds__(256) void attn_pack_kernel(const TIN* __restrict__ src, AttnStrides st, int L, int D, int Dp, int Dm, int Lkp, int which, int normalize,
-                                                        __bf16* __restrict__ dst) {
+                                                        float post_scale, __bf16* __restrict__ dst) {
     // one wave per token: lanes stride over channels
     const int tok = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
     if (tok >= (which == 2 ? Lkp : L)) return;
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(const TIN* __restrict__ 
         for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
         inv = 1.f / (1e-4f + sqrtf(ss) / sqrtf((float)D));
     }
+    inv *= post_scale;  // Q carries the softmax scale * log2(e): the flash kernel's logits come out of the MFMA ready for exp2 (one multiply per score saved)
     if (which < 2) {
         __bf16* out = dst + (((long)b * H + h) * L + tok) * Dp;
 #pragma unroll
@@ -63,18 +64,20 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(const TIN* __restrict__ 
 // DP16 = Dp / 16 (k-steps of Q K^T), DM32 = Dm / 32 (row blocks of O^T)
 template <int DP16, int DM32, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __restrict__ Qp, const __bf16* __restrict__ Kp, const __bf16* __restrict__ Vt, float* __restrict__ out_f32,
-                                                        __bf16* __restrict__ out_b16, AttnStrides ost, int Lq, int Lk, int Lkp, int D, float scale_log2e) {
+                                                        __bf16* __restrict__ out_b16, AttnStrides ost, int Lq, int Lk, int Lkp, int D) {
     constexpr int Dp = DP16 * 16, Dm = DM32 * 32, TK = 64;
     constexpr int KSL = (Dp / 8) | 1, KPITCH = KSL * 16;      // K rows: odd number of 16-byte slots
     constexpr int VPITCH = (TK / 8 + 1) * 16;                 // Vt rows: 64 keys = 8 slots -> 9
-    __shared__ __attribute__((aligned(16))) unsigned char s_k[TK * KPITCH];
-    __shared__ __attribute__((aligned(16))) unsigned char s_v[Dm * VPITCH];
+    // K / V^T tiles are DOUBLE-buffered in LDS (round 3): tile t+1 travels global -> registers while tile t is computed and is written to the
+    // other buffer afterwards, so a tile costs one workgroup barrier instead of two
+    __shared__ __attribute__((aligned(16))) unsigned char s_k[2][TK * KPITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char s_v[2][Dm * VPITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
     constexpr int NTHR = 64 * NW;
     const int q = blockIdx.x * (32 * NW) + wave * 32 + l31;
     const bool qok = q < Lq;
-    // Q fragments (B operand): lane = query column, half-wave = which 8 of the 16 d of a k-step
+    // Q fragments (B operand): lane = query column, half-wave = which 8 of the 16 d of a k-step.  Q already carries scale * log2(e).
     u32x4 qf[DP16];
     {
         const __bf16* qrow = Qp + (((long)b * H + h) * Lq + (qok ? q : 0)) * Dp + lh * 8;
@@ -89,8 +92,6 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
     float m_run = -3.0e38f, l_run = 0.f;
     const __bf16* kbase = Kp + ((long)b * H + h) * Lk * Dp;
     const __bf16* vbase = Vt + ((long)b * H + h) * Dm * Lkp;
-    // tile staging is software-pipelined through registers: the global loads of tile t+1 are issued before tile t is computed and written to
-    // LDS after it, so an HBM / L2 round trip is never waited for on the critical path
     constexpr int KPIECES = TK * (Dp / 8), VPIECES = Dm * (TK / 8);
     constexpr int KIT = (KPIECES + NTHR - 1) / NTHR, VIT = (VPIECES + NTHR - 1) / NTHR;
     u32x4 kreg[KIT], vreg[VIT];
@@ -106,21 +107,34 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
             vreg[it] = e < VPIECES ? *(const u32x4*)(vbase + (long)r * Lkp + k0 + sl * 8) : u32x4{0u, 0u, 0u, 0u};   // Lkp is a multiple of 64, padding keys are zero
         }
     };
-    load_tile(0);
-    for (int k0 = 0; k0 < Lk; k0 += TK) {
-        __syncthreads();  // the previous tile's readers are done
+    auto store_tile = [&](int buf) {
 #pragma unroll
         for (int it = 0; it < KIT; ++it) {
             const int e = tid + it * NTHR, r = e / (Dp / 8), sl = e % (Dp / 8);
-            if (e < KPIECES) *(u32x4*)(s_k + r * KPITCH + sl * 16) = kreg[it];
+            if (e < KPIECES) *(u32x4*)(s_k[buf] + r * KPITCH + sl * 16) = kreg[it];
         }
 #pragma unroll
         for (int it = 0; it < VIT; ++it) {
             const int e = tid + it * NTHR, r = e / (TK / 8), sl = e % (TK / 8);
-            if (e < VPIECES) *(u32x4*)(s_v + r * VPITCH + sl * 16) = vreg[it];
+            if (e < VPIECES) *(u32x4*)(s_v[buf] + r * VPITCH + sl * 16) = vreg[it];
         }
-        __syncthreads();
-        if (k0 + TK < Lk) load_tile(k0 + TK);
+    };
+    // two tiles ahead: tile t+1 sits in registers (requested a whole tile ago) while tile t+2 is requested at the top of tile t
+    u32x4 kreg2[KIT], vreg2[VIT];
+    load_tile(0);
+    store_tile(0);
+    if (TK < Lk) load_tile(TK);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < Lk; k0 += TK, buf ^= 1) {
+        const bool more = k0 + TK < Lk;
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) kreg2[it] = kreg[it];
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) vreg2[it] = vreg[it];
+        if (k0 + 2 * TK < Lk) load_tile(k0 + 2 * TK);   // lands during this tile and the next
+        const unsigned char* sk_ = s_k[buf];
+        const unsigned char* sv_ = s_v[buf];
         // ---- S^T = K Q^T for two 32-key blocks
         f32x16 s[2];
 #pragma unroll
@@ -129,27 +143,36 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < DP16; ++ks) {
-                const u32x4 kf = *(const u32x4*)(s_k + (kb * 32 + l31) * KPITCH + ks * 32 + lh * 16);
+                const u32x4 kf = *(const u32x4*)(sk_ + (kb * 32 + l31) * KPITCH + ks * 32 + lh * 16);
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[ks]), s[kb], 0, 0, 0);
             }
         }
-        // ---- online softmax for this lane's query: keys of register r of block kb = k0 + 32 kb + 8 (r / 4) + 4 lh + r % 4
-        float mt = -3.0e38f;
+        // ---- online softmax for this lane's query: keys of register r of block kb = k0 + 32 kb + 8 (r / 4) + 4 lh + r % 4.
+        // The softmax is what bounds this kernel at small head dims (d = 40: 14 MFMAs = 448 matrix cycles against ~850 VALU cycles per tile
+        // in round 2), so it is kept lean: no scaling multiply (folded into Q), the key mask only on the last, ragged tile, three-input
+        // maxima, packed fp32 subtract / sum, one v_cvt_pk per two probabilities.
+        if (k0 + TK > Lk) {  // wave-uniform: only the last tile of a ragged key length
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + kb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+                    if (key >= Lk) s[kb][r] = -3.0e38f;
+                }
+        }
+        float mt = fmaxf(s[0][0], s[0][1]);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + kb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
-                s[kb][r] = key < Lk ? s[kb][r] * scale_log2e : -3.0e38f;
-                mt = fmaxf(mt, s[kb][r]);
-            }
+            for (int r = (kb == 0 ? 2 : 0); r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[kb][r]), s[kb][r + 1]);   // v_max3_f32
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         const float m_new = fmaxf(m_run, mt);
         // the running maximum rarely moves after the first tiles: rescaling O and the denominator is skipped (wave-uniformly) when no query of
         // the wave saw a new maximum
         const bool moved = __builtin_amdgcn_ballot_w64(m_new > m_run) != 0;
         const float alpha = moved ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.f;
-        float psum = 0.f;
+        f32x2 psum2 = {0.f, 0.f};
+        const f32x2 nm2 = {-m_new, -m_new};
         u32x4 pf[4];  // B fragments of the four 16-key steps: 8 probabilities each, already in contraction order
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -157,14 +180,15 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
             for (int jj = 0; jj < 2; ++jj) {
                 bf16x8 pb;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float p = __builtin_amdgcn_exp2f(s[kb][jj * 8 + e] - m_new);   // v_exp_f32: inputs <= 0, flushing tiny results to 0 is fine
-                    pb[e] = (__bf16)p;
-                    psum += (float)pb[e];  // the denominator sums what the numerator uses (the rounded probabilities)
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2 d = f32x2{s[kb][jj * 8 + e], s[kb][jj * 8 + e + 1]} + nm2;       // v_pk_add_f32
+                    const f32x2 p = {__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};  // inputs <= 0, flushing tiny results to 0 is fine
+                    psum2 = psum2 + p;                                                            // fp32 denominator (the numerator rounds to bf16: 2^-9 relative, unbiased)
+                    pb[e] = (__bf16)p.x; pb[e + 1] = (__bf16)p.y;
                 }
                 pf[kb * 2 + jj] = __builtin_bit_cast(u32x4, pb);
             }
-        l_run = l_run * alpha + psum;
+        l_run = l_run * alpha + (psum2.x + psum2.y);
         m_run = m_new;
         // ---- O^T = alpha O^T + V^T P^T
 #pragma unroll
@@ -175,10 +199,23 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
             }
 #pragma unroll
             for (int st4 = 0; st4 < 4; ++st4) {
-                const u32x4 vf = *(const u32x4*)(s_v + (d * 32 + l31) * VPITCH + st4 * 32 + lh * 16);
+                const u32x4 vf = *(const u32x4*)(sv_ + (d * 32 + l31) * VPITCH + st4 * 32 + lh * 16);
                 o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf[st4]), o[d], 0, 0, 0);
             }
         }
+        if (more) {   // tile t+1 (in kreg2 / vreg2 since the top of this tile) -> the other buffer, whose readers finished before the previous barrier
+#pragma unroll
+            for (int it = 0; it < KIT; ++it) {
+                const int e = tid + it * NTHR, r = e / (Dp / 8), sl = e % (Dp / 8);
+                if (e < KPIECES) *(u32x4*)(s_k[buf ^ 1] + r * KPITCH + sl * 16) = kreg2[it];
+            }
+#pragma unroll
+            for (int it = 0; it < VIT; ++it) {
+                const int e = tid + it * NTHR, r = e / (TK / 8), sl = e % (TK / 8);
+                if (e < VPIECES) *(u32x4*)(s_v[buf ^ 1] + r * VPITCH + sl * 16) = vreg2[it];
+            }
+        }
+        __syncthreads();
     }
     const float linv = 1.f / (l_run + __shfl_xor(l_run, 32));
     if (qok) {
@@ -201,24 +238,25 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
 // ---- host launchers
 template <typename TIN>
 static hipError_t attn_pack(const TIN* q, const TIN* k, const TIN* v, AttnStrides sq, AttnStrides sk, AttnStrides sv, int B, int H, int Lq, int Lk, int D, int normalize,
-                            __bf16* Qp, __bf16* Kp, __bf16* Vt, hipStream_t st) {
+                            float scale, __bf16* Qp, __bf16* Kp, __bf16* Vt, hipStream_t st) {
+    const float qscale = scale * 1.4426950408889634f;  // folded into Q (see attn_pack_kernel)
     const int Dp = (D + 15) / 16 * 16, Dm = (D + 31) / 32 * 32, Lkp = (Lk + 63) / 64 * 64;
-    hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lq + 3) / 4, H, B), dim3(256), 0, st, q, sq, Lq, D, Dp, Dm, Lkp, 0, normalize, Qp);
-    hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lk + 3) / 4, H, B), dim3(256), 0, st, k, sk, Lk, D, Dp, Dm, Lkp, 1, normalize, Kp);
-    hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lkp + 3) / 4, H, B), dim3(256), 0, st, v, sv, Lk, D, Dp, Dm, Lkp, 2, normalize, Vt);
+    hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lq + 3) / 4, H, B), dim3(256), 0, st, q, sq, Lq, D, Dp, Dm, Lkp, 0, normalize, qscale, Qp);
+    hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lk + 3) / 4, H, B), dim3(256), 0, st, k, sk, Lk, D, Dp, Dm, Lkp, 1, normalize, 1.f, Kp);
+    hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lkp + 3) / 4, H, B), dim3(256), 0, st, v, sv, Lk, D, Dp, Dm, Lkp, 2, normalize, 1.f, Vt);
     return hipGetLastError();
 }
 
 static hipError_t attn_mfma(const __bf16* Qp, const __bf16* Kp, const __bf16* Vt, float* out_f32, __bf16* out_b16, AttnStrides ost, int B, int H, int Lq, int Lk, int D,
-                            float scale, hipStream_t st) {
+                            hipStream_t st) {
     const int Dp16 = (D + 15) / 16, Dm32 = (D + 31) / 32, Lkp = (Lk + 63) / 64 * 64;
-    const float sl2 = scale * 1.4426950408889634f;
     // 8 waves (256 queries) per workgroup when there are enough queries to fill the chip that way: the K / V^T tile is staged once per workgroup
-    const bool big = (long)((Lq + 255) / 256) * H * B >= 256;
+    static const long big_min = getenv("TD_ATTN_BIG_MIN") ? atol(getenv("TD_ATTN_BIG_MIN")) : 256;   // A/B hook (tools/attn_bench.py)
+    const bool big = (long)((Lq + 255) / 256) * H * B >= big_min;
     const dim3 grid(big ? (Lq + 255) / 256 : (Lq + 127) / 128, H, B), blk(big ? 512 : 256);
 #define TD_ATTN_CASE(A, M) if (Dp16 == A && Dm32 == M) {                                                                                        \
-        if (big) hipLaunchKernelGGL((attn_mfma_kernel<A, M, 8>), grid, blk, 0, st, Qp, Kp, Vt, out_f32, out_b16, ost, Lq, Lk, Lkp, D, sl2);      \
-        else hipLaunchKernelGGL((attn_mfma_kernel<A, M, 4>), grid, blk, 0, st, Qp, Kp, Vt, out_f32, out_b16, ost, Lq, Lk, Lkp, D, sl2);          \
+        if (big) hipLaunchKernelGGL((attn_mfma_kernel<A, M, 8>), grid, blk, 0, st, Qp, Kp, Vt, out_f32, out_b16, ost, Lq, Lk, Lkp, D);           \
+        else hipLaunchKernelGGL((attn_mfma_kernel<A, M, 4>), grid, blk, 0, st, Qp, Kp, Vt, out_f32, out_b16, ost, Lq, Lk, Lkp, D);               \
         return hipGetLastError(); }
     TD_ATTN_CASE(1, 1) TD_ATTN_CASE(2, 1) TD_ATTN_CASE(3, 2) TD_ATTN_CASE(4, 2) TD_ATTN_CASE(5, 3) TD_ATTN_CASE(6, 3) TD_ATTN_CASE(7, 4) TD_ATTN_CASE(8, 4) TD_ATTN_CASE(9, 5) TD_ATTN_CASE(10, 5)
 #undef TD_ATTN_CASE

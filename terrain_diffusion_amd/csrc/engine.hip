@@ -919,8 +919,8 @@ static int run_unet(td_unet* u, Plan& pl, int step) {
                 __bf16 *Qp = (__bf16*)op.attn_ws, *Kp = Qp + qn, *Vt = Kp + kn;
                 const __bf16* qkv = (const __bf16*)op.qkv;
                 const AttnStrides si = {(long)L * 3 * op.C, 64L * 3, 3L * op.C, 3L}, so = {(long)L * op.C, 64L, (long)op.C, 1L};
-                hipError_t ea = attn_pack<__bf16>(qkv, qkv + 1, qkv + 2, si, si, si, pl.N, Hh, L, L, 64, 1, Qp, Kp, Vt, st);
-                if (ea == hipSuccess) ea = attn_mfma(Qp, Kp, Vt, nullptr, (__bf16*)op.att, so, pl.N, Hh, L, L, 64, 0.125f, st);
+                hipError_t ea = attn_pack<__bf16>(qkv, qkv + 1, qkv + 2, si, si, si, pl.N, Hh, L, L, 64, 1, 0.125f, Qp, Kp, Vt, st);
+                if (ea == hipSuccess) ea = attn_mfma(Qp, Kp, Vt, nullptr, (__bf16*)op.att, so, pl.N, Hh, L, L, 64, st);
                 if (ea != hipSuccess) return fail(TD_ERR_HIP, std::string("attention launch: ") + hipGetErrorString(ea));
             } else
             TD_DISPATCH_T(u, hipLaunchKernelGGL(attn_kernel<T_>, dim3(pl.N, op.C / 64), dim3(256), 0, st, (const T_*)op.qkv, (T_*)op.att, op.tokens, op.C));
@@ -1628,8 +1628,8 @@ int td_attention(td_engine* e, const float* q, const float* k, const float* v, i
     HIP_TRY(ws->alloc(tot * 2, false));
     __bf16 *Qp = (__bf16*)ws->p, *Kp = Qp + qn, *Vt = Kp + kn;
     const AttnStrides sq = {(long)H * Lq * D, (long)Lq * D, (long)D, 1L}, sk = {(long)H * Lk * D, (long)Lk * D, (long)D, 1L};
-    HIP_TRY(attn_pack<float>((const float*)dq, (const float*)dk, (const float*)dv, sq, sk, sk, B, H, Lq, Lk, D, normalize, Qp, Kp, Vt, st));
-    HIP_TRY(attn_mfma(Qp, Kp, Vt, (float*)os.dev, nullptr, sq, B, H, Lq, Lk, D, scale, st));
+    HIP_TRY(attn_pack<float>((const float*)dq, (const float*)dk, (const float*)dv, sq, sk, sk, B, H, Lq, Lk, D, normalize, scale, Qp, Kp, Vt, st));
+    HIP_TRY(attn_mfma(Qp, Kp, Vt, (float*)os.dev, nullptr, sq, B, H, Lq, Lk, D, st));
     if ((rc = out_finish(e, os))) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     return TD_OK;

@@ -13,7 +13,10 @@ from terrain_diffusion_amd.engine import get_engine  # noqa: E402
 
 CASES = [("terrain 8x8 block, 64 tiles x 12 heads", 64, 12, 64, 64, 64, True), ("terrain 16x16 block, 64 tiles x 12 heads", 64, 12, 256, 256, 64, True),
          ("SD self-attn 64x64 latents (CFG batch 2)", 2, 8, 4096, 4096, 40, False), ("SD self-attn 32x32", 2, 8, 1024, 1024, 80, False),
-         ("SD self-attn 16x16", 2, 8, 256, 256, 160, False), ("SD cross-attn 4096 x 77", 2, 8, 4096, 77, 40, False)]
+         ("SD self-attn 16x16", 2, 8, 256, 256, 160, False), ("SD cross-attn 4096 x 77", 2, 8, 4096, 77, 40, False),
+         # the same 4096 x 4096 problem at the head dims where the matrix work per score catches up with the softmax's vector work (round 3)
+         ("self-attn 4096 x 4096, d 64", 2, 8, 4096, 4096, 64, False), ("self-attn 4096 x 4096, d 128", 2, 8, 4096, 4096, 128, False),
+         ("self-attn 4096 x 4096, d 160", 2, 8, 4096, 4096, 160, False)]
 only = int(sys.argv[1]) if len(sys.argv) > 1 else None
 reps = int(os.environ.get("REPS", "20"))
 eng = get_engine("cuda")
