@@ -176,6 +176,19 @@ int td_residual_plus(td_engine* e, const float* packed, const float* lowres_up, 
 /* elev = sign(s) * s^2, s = (r0/r1)*std+mean + lowres_up, cropped to [oi,oi+h) x [oj,oj+w)  (world_pipeline.py:1300,1308-1312).  Device buffers. */
 int td_elev_finish(td_engine* e, const float* packed, const float* lowres_up, int Hp, int Wp, int oi, int oj, int h, int w, float res_mean,
                    float res_std, float* out);
+/* WorldPipeline._compute_climate, per-pixel half (world_pipeline.py:1333-1365): out (5, h, w) = [baseline + lapse * max(elev, 0), coarse channels 3, 4, 5
+ * upsampled, lapse rate] for the pixel box that starts at (i1, j1); feats (5, Hs, Ws) = [sea-level baseline, lapse rate, coarse ch 3, 4, 5] on the coarse
+ * grid whose first cell is (ci1, cj1) in units of S pixels; bilinear with clamped borders = torch grid_sample(align_corners=False, 'border').
+ * Device buffers only. */
+int td_climate_finish(td_engine* e, const float* feats, int Hs, int Ws, const float* elev, int i1, int j1, int h, int w, float S, int ci1, int cj1, float* out);
+
+/* ---- panorama demo (BASELINE configs[0]) -------------------------------------------------------------------- */
+/* One classifier-free-guided DDIM step (annotated_infinite_panorama.py:130-134: pred = uncond + g (cond - uncond); latent = scheduler.step(pred,
+ * t, latent).prev_sample with diffusers' DDIMScheduler, eta = 0): out = sqrt(alpha_prev) (latent - sqrt(1 - alpha_t) pred) / sqrt(alpha_t) +
+ * sqrt(1 - alpha_prev) pred over n elements.  alpha_t / alpha_prev = the schedule's cumulative alphas at this step's timestep and at the next one
+ * (terrain_diffusion_amd.pano.DDIMSchedule).  Device buffers only; `out` may alias `latent`. */
+int td_ddim_cfg_step(td_engine* e, const float* latent, const float* pred_uncond, const float* pred_cond, int64_t n, float guidance_scale, float alpha_t,
+                     float alpha_prev, float* out);
 
 /* ---- attention (MFMA flash kernel, terrain_diffusion_amd/csrc/attn_mfma.hip) -------------------------------------------------
  * out = softmax(scale * Q K^T) V per (batch, head); q: [B][H][Lq][D], k / v: [B][H][Lk][D], out: [B][H][Lq][D], fp32 at the boundary, bf16

@@ -62,6 +62,8 @@ _SIGS = {
     "td_resample2d": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
     "td_residual_plus": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
     "td_elev_finish": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
+    "td_ddim_cfg_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, _P]),
+    "td_climate_finish": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _P]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -174,9 +174,10 @@ def local_baseline_temperature(T, e, win=3, beta_clip=(-0.012, 0.0), fallback_be
 
 
 @torch.no_grad()
-def compute_climate(coarse, i1, j1, i2, j2, elev, scale):
+def compute_climate(coarse, i1, j1, i2, j2, elev, scale, engine=None):
     """WorldPipeline._compute_climate (world_pipeline.py:1315-1365): (5, h, w) = realistic temperature, three climate channels, lapse rate.
-    Small (a few hundred coarse cells): device torch ops (pooling + grid_sample), no custom kernel."""
+    The windowed regression runs on a few hundred coarse cells (device torch pooling ops); everything per output pixel is one HIP kernel
+    (td_climate_finish)."""
     S = 32 * scale
     ci1, cj1 = i1 // S, j1 // S
     ci2, cj2 = -((-i2) // S), -((-j2) // S)
@@ -189,11 +190,12 @@ def compute_climate(coarse, i1, j1, i2, j2, elev, scale):
     base, beta = local_baseline_temperature(cmap[2], celev, win=win, fallback_threshold=0.02)
     central = cmap[:, win // 2:-(win // 2), win // 2:-(win // 2)]
     Hs, Ws = base.shape[-2:]
-    ii, jj = torch.meshgrid(torch.arange(i1, i2, device=dev), torch.arange(j1, j2, device=dev), indexing="ij")
-    u = (ii + 0.5) / S - ci1 + 0.5
-    v = (jj + 0.5) / S - cj1 + 0.5
-    grid = torch.stack([(v + 0.5) * 2 / Ws - 1, (u + 0.5) * 2 / Hs - 1], dim=-1).unsqueeze(0)
-    feats = torch.cat([base[None], beta[None], central], dim=0).unsqueeze(0)
-    up = torch.nn.functional.grid_sample(feats, grid, mode="bilinear", padding_mode="border", align_corners=False).squeeze(0)
-    temp = up[0] + up[1] * torch.clamp(elev, min=0)
-    return torch.stack([temp, up[2 + 3], up[2 + 4], up[2 + 5], up[1]])
+    # per-pixel half (grid, grid_sample of the features, lapse-rate temperature, stack): one pass of climate_finish_kernel over the request
+    feats = torch.stack([base, beta, central[3], central[4], central[5]]).contiguous()
+    elev = elev.to(torch.float32).contiguous()
+    h, w = i2 - i1, j2 - j1
+    out = torch.empty((5, h, w), dtype=torch.float32, device=dev)
+    from .engine import get_engine
+    eng = engine if engine is not None else get_engine(dev)
+    check(lib().td_climate_finish(eng._h, ptr(feats), int(Hs), int(Ws), ptr(elev), int(i1), int(j1), int(h), int(w), float(S), int(ci1), int(cj1), ptr(out)))
+    return out

@@ -61,6 +61,47 @@ __global__ void residual_plus_kernel(const float* __restrict__ packed, const flo
 
 }  // namespace td
 
+// ---- climate composition (round 3): WorldPipeline._compute_climate's per-pixel half (world_pipeline.py:1333-1365) in ONE pass -- the pixel grid,
+// the normalised sampling grid, torch.nn.functional.grid_sample(bilinear, padding 'border', align_corners=False) of the coarse features, the
+// lapse-rate temperature and the channel stack.  feats: (5, Hs, Ws) = sea-level baseline, lapse rate, and the coarse map's channels 3, 4, 5
+// (the other three of the reference's eight sampled features are never used).  Reads 4 B and writes 20 B per output pixel; the torch form
+// materialises the (h, w, 2) grid and eight upsampled planes.  The coordinate arithmetic repeats torch's fp32 steps one by one
+// (grid_sampler_unnormalize, clip_coordinates) so that the result agrees with the reference's to the last bits of the blend weights.
+namespace td {
+
+__global__ void climate_finish_kernel(const float* __restrict__ feats, const float* __restrict__ elev, float* __restrict__ out, int Hs, int Ws, int i1, int j1,
+                                      int h, int w, float S, int ci1, int cj1) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= h * w) return;
+    const int r = idx / w, c = idx % w;
+    // u = (ii + 0.5) / S - ci1 + 0.5 ; grid_y = (u + 0.5) * 2 / H_src - 1          (world_pipeline.py:1341-1345, fp32 tensors)
+    const float u = ((float)(i1 + r) + 0.5f) / S - (float)ci1 + 0.5f, v = ((float)(j1 + c) + 0.5f) / S - (float)cj1 + 0.5f;
+    const float gy = (u + 0.5f) * 2.f / (float)Hs - 1.f, gx = (v + 0.5f) * 2.f / (float)Ws - 1.f;
+    // grid_sample, align_corners=False: x = ((g + 1) * size - 1) / 2, padding_mode='border': clamp to [0, size - 1]
+    float y = ((gy + 1.f) * (float)Hs - 1.f) / 2.f, x = ((gx + 1.f) * (float)Ws - 1.f) / 2.f;
+    y = fminf(fmaxf(y, 0.f), (float)(Hs - 1)); x = fminf(fmaxf(x, 0.f), (float)(Ws - 1));
+    const float y0f = floorf(y), x0f = floorf(x);
+    const int y0 = (int)y0f, x0 = (int)x0f, y1 = y0 + 1, x1 = x0 + 1;
+    const float ty = y - y0f, tx = x - x0f;
+    const float wnw = (1.f - tx) * (1.f - ty), wne = tx * (1.f - ty), wsw = (1.f - tx) * ty, wse = tx * ty;   // torch: (ix_se - ix) * (iy_se - iy) ...
+    const bool iy1 = y1 < Hs, ix1 = x1 < Ws;   // the far corner of a clamped coordinate falls outside: its weight is 0, torch skips it
+    float f[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float* p = feats + (size_t)k * Hs * Ws;
+        float a = p[y0 * Ws + x0] * wnw;
+        if (ix1) a += p[y0 * Ws + x1] * wne;
+        if (iy1) a += p[y1 * Ws + x0] * wsw;
+        if (iy1 && ix1) a += p[y1 * Ws + x1] * wse;
+        f[k] = a;
+    }
+    const size_t hw = (size_t)h * w;
+    out[idx] = f[0] + f[1] * fmaxf(elev[idx], 0.f);   // temp_baseline + beta * max(elev, 0)
+    out[hw + idx] = f[2]; out[2 * hw + idx] = f[3]; out[3 * hw + idx] = f[4]; out[4 * hw + idx] = f[1];
+}
+
+}  // namespace td
+
 // ---- synthetic conditioning map: gradient-noise FBm with the structure of FastNoiseLite's Perlin / FBm path that
 // terrain_diffusion/inference/synthetic_map.py:182-236 drives (frequency, octaves, lacunarity 2, gain 0.5, one integer seed per channel),
 // followed by the 64-knot quantile transfer of perlin_transform.py:41-45 (np.interp with clamped ends).  pyfastnoiselite is not available in

@@ -1591,6 +1591,29 @@ int td_elev_finish(td_engine* e, const float* packed, const float* lowres_up, in
     return TD_OK;
 }
 
+int td_ddim_cfg_step(td_engine* e, const float* latent, const float* pred_uncond, const float* pred_cond, int64_t n, float guidance_scale, float alpha_t,
+                     float alpha_prev, float* out) {
+    DevGuard dg_(e->device);
+    if (n < 1 || !(alpha_t > 0.f) || !(alpha_t <= 1.f) || !(alpha_prev > 0.f) || !(alpha_prev <= 1.f)) return fail(TD_ERR_ARG, "td_ddim_cfg_step: bad arguments");
+    if (!is_device_ptr(latent) || !is_device_ptr(pred_uncond) || !is_device_ptr(pred_cond) || !is_device_ptr(out)) return fail(TD_ERR_ARG, "td_ddim_cfg_step: device buffers only");
+    // the scheduler's scalars in fp32 from the (fp32) cumulative alphas, as torch computes alpha ** 0.5 on 0-d fp32 tensors
+    hipLaunchKernelGGL(ddim_cfg_step_kernel, grid1((size_t)n), dim3(256), 0, e->stream, latent, pred_uncond, pred_cond, out, (size_t)n, guidance_scale,
+                       sqrtf(1.f - alpha_t), sqrtf(alpha_t), sqrtf(alpha_prev), sqrtf(1.f - alpha_prev));
+    HIP_TRY(hipGetLastError());
+    std::vector<Buf> none;
+    return end_call(e, none, true);
+}
+
+int td_climate_finish(td_engine* e, const float* feats, int Hs, int Ws, const float* elev, int i1, int j1, int h, int w, float S, int ci1, int cj1, float* out) {
+    DevGuard dg_(e->device);
+    if (!is_device_ptr(feats) || !is_device_ptr(elev) || !is_device_ptr(out)) return fail(TD_ERR_ARG, "td_climate_finish: device buffers only");
+    if (Hs < 1 || Ws < 1 || h < 1 || w < 1 || !(S > 0.f)) return fail(TD_ERR_ARG, "td_climate_finish: bad geometry");
+    hipLaunchKernelGGL(climate_finish_kernel, grid1((size_t)h * w), dim3(256), 0, e->stream, feats, elev, out, Hs, Ws, i1, j1, h, w, S, ci1, cj1);
+    HIP_TRY(hipGetLastError());
+    std::vector<Buf> none;
+    return end_call(e, none, true);
+}
+
 // ---- synthetic conditioning map channel
 int td_perlin_map(td_engine* e, int rows, int cols, int i1, int j1, int seed, float frequency, int octaves, float lacunarity, float gain,
                   const float* src_quantiles, const float* dst_quantiles, int n_quantiles, float* out) {

@@ -255,6 +255,19 @@ __global__ void consistency_post_kernel(const float* __restrict__ xt, const floa
     }
 }
 
+// ------------------------------------------------------------------------------------------------ DDIM + classifier-free guidance (configs[0])
+// annotated_infinite_panorama.py:130-134 in one pass: pred = uncond + g (cond - uncond); x0 = (x - sqrt(1 - a_t) pred) / sqrt(a_t);
+// out = sqrt(a_prev) x0 + sqrt(1 - a_prev) pred (DDIM, eta = 0; Song et al. 2021 eq. 12 as diffusers' DDIMScheduler.step runs it for the SD-v1.5
+// config).  The four scalars are computed on the host from the schedule (terrain_diffusion_amd/pano.py).
+__global__ void ddim_cfg_step_kernel(const float* __restrict__ x, const float* __restrict__ uncond, const float* __restrict__ cond, float* __restrict__ out, size_t n,
+                                     float g, float sqrt_one_minus_at, float sqrt_at, float sqrt_aprev, float sqrt_one_minus_aprev) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float u = uncond[i], e = u + g * (cond[i] - u);
+    const float x0 = (x[i] - sqrt_one_minus_at * e) / sqrt_at;
+    out[i] = sqrt_aprev * x0 + sqrt_one_minus_aprev * e;
+}
+
 // ------------------------------------------------------------------------------------------------ portable noise
 // portable_rng.py:22-74: 64-bit LCG, XSH-RR output of the post-advance state, Marsaglia polar with rejection.
 // Parallel form: thread t of a workgroup owns candidate pairs [round*R + t*PPT, +PPT) via LCG jump-ahead; accepted

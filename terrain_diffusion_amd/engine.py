@@ -53,6 +53,10 @@ class Engine:
         if stream is not None and not h:
             raise ValueError("the legacy default (NULL) stream cannot carry the engine's captured graphs: create a torch.cuda.Stream()")
         check(lib().td_engine_set_stream(self._h, C.c_void_p(int(h)) if h else None))
+        if h:
+            _SHARED_STREAM[self.device_id] = int(h)
+        else:
+            _SHARED_STREAM.pop(self.device_id, None)
 
     def on_stream(self, stream, asynchronous=True):
         """Context manager: run the engine on `stream`; with asynchronous=True calls on device tensors only enqueue (option "async")."""
@@ -92,6 +96,9 @@ def get_engine(device=None) -> Engine:
     return _engines[idx]
 
 
+_SHARED_STREAM = {}   # device index -> raw handle of the caller stream the engine currently launches on (Engine.set_stream)
+
+
 def ptr(t):
     """raw pointer of a contiguous fp32 torch tensor / numpy array (host or device), or None.
     C-ABI contract: device buffers handed to the engine must be COMPLETE (the engine launches on its own non-blocking stream and
@@ -104,7 +111,10 @@ def ptr(t):
         return C.c_void_p(t.ctypes.data)
     assert t.is_contiguous()
     if t.is_cuda:
-        torch.cuda.current_stream(t.device).synchronize()
+        cs = torch.cuda.current_stream(t.device)
+        # ... unless the engine has been put ON that stream (Engine.set_stream): then stream order is all that is needed
+        if _SHARED_STREAM.get(t.device.index if t.device.index is not None else torch.cuda.current_device()) != cs.cuda_stream:
+            cs.synchronize()
     return C.c_void_p(t.data_ptr())
 
 

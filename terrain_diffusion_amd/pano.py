@@ -80,3 +80,50 @@ def pack(values_chw, weight_hw):
     """values (C,H,W), weight (H,W) -> (C+1,H,W) = [values * weight, weight] (annotated_infinite_panorama.py:148-150)."""
     w = weight_hw[None]
     return torch.cat([values_chw * w, w], dim=0)
+
+
+class DDIMSchedule:
+    """The scheduler of the panorama demo (annotated_infinite_panorama.py:112-113: DDIMScheduler.from_config(SD-v1.5 config); set_timesteps(N)):
+    1000 training steps, scaled-linear betas 0.00085 .. 0.012, 'leading' spacing with steps_offset 1, set_alpha_to_one False, epsilon prediction,
+    eta 0.  Host scalars only; the update itself is td_ddim_cfg_step.  The arithmetic is diffusers' (absent here): restated from the published
+    algorithm, parity unpinned (oracle/ddim.py says what is checked)."""
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.num_train_timesteps, self.steps_offset = int(num_train_timesteps), int(steps_offset)
+        self.timesteps, self.num_inference_steps = None, None
+
+    def set_timesteps(self, num_inference_steps):
+        self.num_inference_steps = int(num_inference_steps)
+        ratio = self.num_train_timesteps // self.num_inference_steps
+        self.timesteps = torch.from_numpy((np.arange(self.num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)) + self.steps_offset
+        return self
+
+    def scale_model_input(self, sample, t=None):
+        return sample
+
+    def alphas(self, t):
+        prev_t = int(t) - self.num_train_timesteps // self.num_inference_steps
+        return float(self.alphas_cumprod[int(t)]), float(self.alphas_cumprod[prev_t] if prev_t >= 0 else self.alphas_cumprod[0])
+
+
+def denoise(latent, timesteps, unet_fn, schedule, guidance_scale=7.5, engine=None):
+    """annotated_infinite_panorama.py:125-134 on the engine: classifier-free-guided DDIM steps on a (1, C, H, W) device latent.
+    unet_fn(inp (2, C, H, W), t) -> (2, C, H, W) is the caller's denoiser ([uncond, cond] halves; the demo's is SD-v1.5's UNet2DCondition, which is
+    third-party and not part of this package); the guidance mix and the scheduler update are one HIP kernel per step (td_ddim_cfg_step)."""
+    from ._lib import lib, check
+    from .engine import get_engine, ptr
+    latent = torch.as_tensor(latent, dtype=torch.float32)
+    if not latent.is_cuda:
+        latent = latent.cuda()
+    latent = latent.contiguous().clone()
+    eng = engine if engine is not None else get_engine(latent.device)
+    n = latent.numel()
+    for t in timesteps:
+        inp = schedule.scale_model_input(torch.cat([latent] * 2), t)
+        pred = torch.as_tensor(unet_fn(inp, t), dtype=torch.float32).to(latent.device).contiguous()
+        a_t, a_prev = schedule.alphas(t)
+        check(lib().td_ddim_cfg_step(eng._h, ptr(latent), ptr(pred[:1]), ptr(pred[1:]), n, float(guidance_scale), a_t, a_prev, ptr(latent)))
+    return latent

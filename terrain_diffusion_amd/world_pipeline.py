@@ -272,7 +272,7 @@ class WorldPipeline:
         return composition.compute_elev(self.engine, residual_map, self.latents, i1, j1, i2, j2, scale, self.kwargs["residual_mean"], self.kwargs["residual_std"])
 
     def _compute_climate(self, i1, j1, i2, j2, elev, scale):
-        return composition.compute_climate(self.coarse, i1, j1, i2, j2, elev, scale)
+        return composition.compute_climate(self.coarse, i1, j1, i2, j2, elev, scale, engine=self.engine)
 
     def get(self, i1, j1, i2, j2, with_climate=True):
         """{'elev': (H, W) metres, 'climate': (5, H, W) or None} for the pixel box [i1,i2) x [j1,j2); device tensors."""

@@ -255,3 +255,26 @@ def test_caller_supplied_stream_orders_engine_work_without_host_sync(td):
     assert torch.equal(out, ref)
     assert eng.stream != s.cuda_stream                  # the context restored the engine's own stream
     m.close()
+
+
+def test_pano_denoise_ddim_cfg_step_vs_oracle(td):
+    """BASELINE configs[0] (annotated_infinite_panorama.py:125-134): the classifier-free-guidance mix + DDIM update on the engine
+    (td_ddim_cfg_step, driven by pano.denoise with a stand-in denoiser -- SD-v1.5's UNet2DCondition is third-party) against oracle/ddim.py's
+    restatement of the published algorithm, 4 steps on 2 tiles' worth of 64x64 latents as configs[0] words it.  The DDIM arithmetic itself is
+    unpinned (diffusers absent; oracle/ddim.py header); this pins the HIP kernel to the restatement: <= 2 ulp-level fp32 differences."""
+    import torch
+    from oracle import ddim, rng
+    from terrain_diffusion_amd import pano
+    sch = pano.DDIMSchedule().set_timesteps(4)
+    # (torch.cumprod and np.cumprod round the 1000-term fp32 product differently in the last place)
+    assert sch.timesteps.tolist() == list(ddim.timesteps(4)) and np.allclose(sch.alphas_cumprod.numpy(), ddim.alphas_cumprod(), rtol=2e-6, atol=0)
+    lat = rng.standard_normal(81, (1, 4, 64, 128)).astype(np.float32)       # two 64x64 latent tiles side by side
+
+    def stub_np(inp, t):   # a deterministic "U-Net": mixes the input with a timestep-dependent field, different for the two CFG halves
+        f = np.float32(np.sin(0.01 * t))
+        return np.concatenate([inp[:1] * np.float32(0.3) + f, inp[1:] * np.float32(0.35) - f * np.float32(0.5)]).astype(np.float32)
+    ref = ddim.denoise(lat, ddim.timesteps(4), 4, stub_np, guidance_scale=7.5, acp=sch.alphas_cumprod.numpy())
+    got = pano.denoise(torch.from_numpy(lat), sch.timesteps, lambda inp, t: torch.from_numpy(stub_np(inp.cpu().numpy(), int(t))), sch, guidance_scale=7.5)
+    err = rel_rms(got.cpu().numpy(), ref)
+    print(f"pano.denoise (4 DDIM steps, CFG 7.5) vs oracle/ddim.py: rel-RMS {err:.2e}")
+    assert err < 2e-6
