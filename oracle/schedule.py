@@ -54,11 +54,11 @@ def precondition_outputs(sample, model_output, sigma, sigma_data=0.5):
 
 
 def step_coefficients(sigmas, i, order):
-    """fp32 scalars of one dpmsolver++ midpoint update at step i (alpha_t == 1):
-    x_next = a*x + b*m0 + c*m1, derived term-by-term from dpmsolver.py:481-482 / :529-540.
-    Returns python floats (a, b0, b1, inv_r0) such that
-      order 1: x = a*x - b0*m0              with a = s_t/s_s, b0 = exp(-h)-1
-      order 2: x = a*x - b0*m0 - 0.5*b0*D1,  D1 = inv_r0*(m0-m1)
+    """fp32 scalars of one dpmsolver++ update at step i (alpha_t == 1), derived term-by-term from dpmsolver.py:481-482 / :529-540 / :586-613.
+    Returns (a, b0, inv_r0, third) with
+      order 1: x = a*x - b0*m0                                   a = s_t/s_s, b0 = exp(-h)-1
+      order 2: x = a*x - b0*m0 - 0.5*b0*D1,                       D1 = inv_r0*(m0-m1)
+      order 3: x = a*x - b0*D0 + c1*D1 - c2*D2                    third = (inv_r1, r0/(r0+r1), 1/(r0+r1), c1, c2), see dpm_step
     """
     s_t, s_s = sigmas[i + 1], sigmas[i]
     lam_t = torch.log(torch.tensor(1)) - torch.log(s_t)
@@ -66,22 +66,32 @@ def step_coefficients(sigmas, i, order):
     h = lam_t - lam_s
     a = s_t / s_s
     b0 = torch.exp(-h) - 1.0
-    inv_r0 = None
-    if order == 2:
+    inv_r0, third = None, None
+    if order >= 2:
         lam_s1 = torch.log(torch.tensor(1)) - torch.log(sigmas[i - 1])
         h0 = lam_s - lam_s1
         r0 = h0 / h
         inv_r0 = 1.0 / r0
-    return a, b0, inv_r0
+        if order == 3:
+            lam_s2 = torch.log(torch.tensor(1)) - torch.log(sigmas[i - 2])
+            r1 = (lam_s1 - lam_s2) / h
+            third = (1.0 / r1, r0 / (r0 + r1), 1.0 / (r0 + r1), (torch.exp(-h) - 1.0) / h + 1.0, (torch.exp(-h) - 1.0 + h) / h ** 2 - 0.5)
+    return a, b0, inv_r0, third
 
 
-def dpm_step(sigmas, i, order, sample, model_output, m_prev, sigma_data=0.5):
-    """One scheduler.step(): returns (prev_sample, x0_pred).  m_prev = previous step's x0_pred."""
+def dpm_step(sigmas, i, order, sample, model_output, m_prev, sigma_data=0.5, m_prev2=None):
+    """One scheduler.step(): returns (prev_sample, x0_pred).  m_prev / m_prev2 = the x0 predictions of the previous two steps."""
     m0 = precondition_outputs(sample, model_output, sigmas[i], sigma_data)
-    a, b0, inv_r0 = step_coefficients(sigmas, i, order)
+    a, b0, inv_r0, third = step_coefficients(sigmas, i, order)
     if order == 1:
         x = a * sample - (1 * b0) * m0
-    else:
+    elif order == 2:
         d1 = inv_r0 * (m0 - m_prev)
         x = a * sample - (1 * b0) * m0 - 0.5 * (1 * b0) * d1
+    else:   # dpmsolver.py:598-613
+        inv_r1, f01, inv_r01, c1, c2 = third
+        d1_0, d1_1 = inv_r0 * (m0 - m_prev), inv_r1 * (m_prev - m_prev2)
+        d1 = d1_0 + f01 * (d1_0 - d1_1)
+        d2 = inv_r01 * (d1_0 - d1_1)
+        x = a * sample - (1 * b0) * m0 + (1 * c1) * d1 - (1 * c2) * d2
     return x, m0

@@ -96,14 +96,14 @@ def initial_noise_field(seed, H, W, channels=5, y0=0, x0=0):
 def sample_base_diffusion_tiled(model, shape, cond_inputs, *, steps=20, tile_size=64, noise_seed=42 + 5819,
                                 cond_means=None, cond_stds=None, histogram_raw=None, noise_level=0.0,
                                 sigma_min=0.002, sigma_max=80.0, sigma_data=0.5, rho=7.0,
-                                tiles=None, return_parts=False, guide_model=None, guidance_scale=1.0):
+                                tiles=None, return_parts=False, guide_model=None, guidance_scale=1.0, solver_order=2):
     """sample_diffusion_base.py:115-168 (B must be 1).  `tiles` optionally restricts to a subset of
     (ic, jc) tile indices (used for sharding tests); returns output/output_weights/sigma_data or parts."""
     B, C, H, W = shape
     assert B == 1
     stride = tile_size // 2
     sigmas, _ = schedule.karras_sigmas(steps, sigma_min, sigma_max, rho)
-    orders = schedule.solver_orders(steps)
+    orders = schedule.solver_orders(steps, solver_order=solver_order)
     weights = linear_weight_window(tile_size)[None, None]
     output = torch.zeros(shape)
     output_weights = torch.zeros(shape)
@@ -121,7 +121,7 @@ def sample_base_diffusion_tiled(model, shape, cond_inputs, *, steps=20, tile_siz
             else:
                 tile_cond = [cond_inputs]
             x = initial_noise[..., i0:i0 + tile_size, j0:j0 + tile_size]
-            m_prev = None
+            m_prev = m_prev2 = None
             for i in range(steps):
                 sigma = sigmas[i]
                 xin = schedule.precondition_inputs(x, sigma, sigma_data)
@@ -130,7 +130,8 @@ def sample_base_diffusion_tiled(model, shape, cond_inputs, *, steps=20, tile_siz
                 if guide_model is not None and guidance_scale != 1.0:   # autoguidance, sample_diffusion_base.py:155-160
                     F_g = guide_model(xin, cn, tile_cond)
                     F_ = F_g + guidance_scale * (F_ - F_g)
-                x, m_prev = schedule.dpm_step(sigmas, i, orders[i], x, F_, m_prev, sigma_data)
+                x, m0_ = schedule.dpm_step(sigmas, i, orders[i], x, F_, m_prev, sigma_data, m_prev2=m_prev2)
+                m_prev, m_prev2 = m0_, m_prev
             output[..., i0:i0 + tile_size, j0:j0 + tile_size] += x * weights
             output_weights[..., i0:i0 + tile_size, j0:j0 + tile_size] += weights
     if return_parts:

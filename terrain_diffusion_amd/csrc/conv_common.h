@@ -150,6 +150,25 @@ __device__ __forceinline__ float epilogue4(const ConvParams& p, int n, int y, in
         }
     }
     float ss = 0.f;
+    if (p.epi == EPI_DPM_STEP) {
+        // v = F, the model output: one DPM-Solver++ step per (pixel, channel) in the arithmetic (and operation order) of dpm_step_kernel
+        const size_t HW = (size_t)p.H * p.W, pl_ = (size_t)y * p.W + x;
+        const SchedCoef k = p.dpm_k;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (co + q < p.Cout) {
+                const size_t xi = ((size_t)n * p.Cout + (co + q)) * HW + pl_;
+                const float xs = p.dpm_x[xi];
+                float xn, m0;
+                const float m1v = (k.order == 1 && !p.dpm_m2) ? 0.f : p.dpm_m1[xi];
+                dpm_update(k, xs, v[q], m1v, k.order == 3 ? p.dpm_m2[xi] : 0.f, xn, m0);
+                p.dpm_x[xi] = xn;
+                if (p.dpm_m2) p.dpm_m2[xi] = m1v;   // history shifts: m2 <- m1 <- m0
+                p.dpm_m1[xi] = m0;
+                if (!k.last) ((T*)p.dpm_xin)[(size_t)pix * p.dpm_xin_cstride + co + q] = (T)(xn * k.c_in_next);
+            }
+        return 0.f;
+    }
     if (p.out_f32) {
         float* o = (float*)p.out + (size_t)pix * p.out_cstride + co;
 #pragma unroll

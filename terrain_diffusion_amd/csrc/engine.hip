@@ -218,13 +218,14 @@ struct Plan {
     float* F = nullptr;        // NHWC fp32 model output, stride 8
     float* partial = nullptr;
     // sampler state
-    Buf x, m1, xt, cond, emb, cvec, tsteps;
+    Buf x, m1, m2, xt, cond, emb, cvec, tsteps;
     int cvec_rows = 0;
     // graph cache for the EDM loop
     hipGraphExec_t graph = nullptr;
     std::vector<float> graph_sigmas;
     float graph_sigma_data = 0.f;
     int graph_solver_order = 0;
+    int graph_fuse = -1;       // engine option "fuse_solver" the graph was captured under
     const void* graph_guide = nullptr;       // guide plan / its modulation buffer / scale the captured graph was built with (autoguidance)
     const void* graph_guide_cvec = nullptr;
     float graph_gscale = 0.f;
@@ -842,8 +843,8 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
         for (auto& op : pl.ops) if (op.kind == Op::CONV) op.p.partial = pl.partial;
     }
     const size_t xbytes = (size_t)N * std::max(u->cfg.in_channels, u->cfg.out_channels) * H * W * 4;
-    pl.x.reset(new DevBuf()); pl.m1.reset(new DevBuf()); pl.xt.reset(new DevBuf()); pl.cond.reset(new DevBuf());
-    HIP_TRY(pl.x->alloc(xbytes)); HIP_TRY(pl.m1->alloc(xbytes)); HIP_TRY(pl.xt->alloc(xbytes));
+    pl.x.reset(new DevBuf()); pl.m1.reset(new DevBuf()); pl.m2.reset(new DevBuf()); pl.xt.reset(new DevBuf()); pl.cond.reset(new DevBuf());
+    HIP_TRY(pl.x->alloc(xbytes)); HIP_TRY(pl.m1->alloc(xbytes)); HIP_TRY(pl.m2->alloc(xbytes)); HIP_TRY(pl.xt->alloc(xbytes));
     HIP_TRY(pl.cond->alloc((size_t)N * std::max(1, u->cond_row_len) * 4));
     HIP_TRY(hipDeviceSynchronize());  // buffer memsets ran on the null stream; the engine stream is non-blocking
     pl.bytes += 3 * xbytes;
@@ -885,7 +886,8 @@ static int compute_cvecs(td_unet* u, Plan& pl, const std::vector<float>& t_steps
 }
 
 // runs the conv stack: xin -> F, using modulation vectors of `step`
-static int run_unet(td_unet* u, Plan& pl, int step) {
+// `fuse` (EDM sampler): the output conv runs the DPM-Solver++ update of this step in its epilogue (EPI_DPM_STEP) instead of writing F
+static int run_unet(td_unet* u, Plan& pl, int step, const SchedCoef* fuse = nullptr) {
     hipStream_t st = u->eng->stream;
     const float* cbase = (const float*)pl.cvec->p + (size_t)step * pl.N * u->c_total;
     const bool prof = u->eng->option("profile", 0) != 0;
@@ -930,6 +932,9 @@ static int run_unet(td_unet* u, Plan& pl, int step) {
         }
         ConvParams p = op.p;
         if (op.cvec_off >= 0) p.cvec = cbase + op.cvec_off;
+        if (fuse && &op == &pl.ops.back()) {   // the output conv (EPI_PLAIN, fp32 F): results go straight into the solver state
+            p.epi = EPI_DPM_STEP; p.dpm_x = (float*)pl.x->p; p.dpm_m1 = (float*)pl.m1->p; p.dpm_m2 = u->eng->option("solver_order", 2) == 3 ? (float*)pl.m2->p : nullptr; p.dpm_xin = pl.xin; p.dpm_xin_cstride = u->chunk; p.dpm_k = *fuse;
+        }
         mark();
         hipError_t e = op.flavor == 3 ? launch_conv_pp(p, u->dt, op.bn, u->eng->n_cus, st)
                        : op.flavor == 2 ? launch_conv_glds(p, u->dt, op.narrow, op.bn, op.glds_variant, st) : launch_conv(p, u->dt, op.narrow, op.bn, 0, st);
@@ -1182,20 +1187,30 @@ static void dpm_coefs(const float* sig, int n_steps, float sigma_data, int solve
         k.c_skip = (sd * sd) / (s * s + sd * sd);
         k.c_out = s * sd / sqrtf(s * s + sd * sd);
         const bool final = (i == n_steps - 1);
-        k.order = (solver_order < 2 || lower < 1 || final) ? 1 : 2;  // dpmsolver.py:688-715 (lower_order_final) with config.solver_order
+        const bool second = (i == n_steps - 2) && n_steps < 15;   // lower_order_second (dpmsolver.py:694-696; lower_order_final is the released setting)
+        // dpmsolver.py:703-708 with config.solver_order and lower_order_final
+        k.order = (solver_order < 2 || lower < 1 || final) ? 1 : ((solver_order == 2 || lower < 2 || second) ? 2 : 3);
         const float lam_t = 0.f - logf(st), lam_s = 0.f - logf(s);
         const float h = lam_t - lam_s;
         k.a = st / s;
         k.b0 = expf(-h) - 1.0f;
-        k.inv_r0 = 0.f;
-        if (k.order == 2) {
+        k.inv_r0 = 0.f; k.inv_r1 = 0.f; k.f01 = 0.f; k.inv_r01 = 0.f; k.c1 = 0.f; k.c2 = 0.f;
+        if (k.order >= 2) {
             const float lam_s1 = 0.f - logf(sig[i - 1]);
             const float h0 = lam_s - lam_s1;
-            k.inv_r0 = 1.0f / (h0 / h);
+            const float r0 = h0 / h;
+            k.inv_r0 = 1.0f / r0;
+            if (k.order == 3) {   // dpmsolver.py:586-613
+                const float lam_s2 = 0.f - logf(sig[i - 2]);
+                const float r1 = (lam_s1 - lam_s2) / h;
+                k.inv_r1 = 1.0f / r1; k.f01 = r0 / (r0 + r1); k.inv_r01 = 1.0f / (r0 + r1);
+                k.c1 = (expf(-h) - 1.0f) / h + 1.0f;
+                k.c2 = (expf(-h) - 1.0f + h) / (h * h) - 0.5f;
+            }
         }
         k.last = final ? 1 : 0;
         k.c_in_next = final ? 0.f : 1.f / sqrtf(st * st + sd * sd);
-        if (lower < 2) ++lower;
+        if (lower < solver_order) ++lower;
         ks[i] = k;
     }
 }
@@ -1251,7 +1266,7 @@ static int sample_edm_lane(td_unet* u, td_unet* guide, float gscale, int n, int 
     }
     std::vector<SchedCoef> ks;
     const int solver_order = (int)e->option("solver_order", 2);
-    if (solver_order != 1 && solver_order != 2) return fail(TD_ERR_ARG, "solver_order must be 1 or 2");
+    if (solver_order < 1 || solver_order > 3) return fail(TD_ERR_ARG, "solver_order must be 1, 2 or 3");
     dpm_coefs(sigmas_host, n_steps, sigma_data, solver_order, ks);
     const float c_in0 = 1.f / sqrtf(sigmas_host[0] * sigmas_host[0] + sigma_data * sigma_data);
 
@@ -1261,11 +1276,16 @@ static int sample_edm_lane(td_unet* u, td_unet* guide, float gscale, int n, int 
             TD_DISPATCH_T(u, hipLaunchKernelGGL(prep_input_kernel<T_>, grid1((size_t)n * HW), dim3(256), 0, st, (const float*)pl->x->p, (T_*)gpl->xin, n, C, HW, u->chunk, c_in0, Cin));
         }
         const float* Fg = gpl ? (const float*)gpl->F : nullptr;
+        // north_star: "the per-tile EDM scheduler step fused into the epilogue".  Without a guide model the solver update of step i runs in the
+        // epilogue of the U-Net's output conv (option "fuse_solver", default on; bit-identical to the separate kernel: same arithmetic on the same
+        // fp32 F); with autoguidance the update needs BOTH models' outputs and stays a kernel of its own.
+        const bool fuse = !gpl && e->option("fuse_solver", 1) != 0 && pl->ops.back().kind == Op::CONV && pl->ops.back().p.epi == EPI_PLAIN && pl->ops.back().p.out_f32;
         for (int i = 0; i < n_steps; ++i) {
-            int r = run_unet(u, *pl, i);
+            int r = run_unet(u, *pl, i, fuse ? &ks[i] : nullptr);
             if (r) return r;
+            if (fuse) continue;
             if (gpl && (r = run_unet(guide, *gpl, i))) return r;
-            TD_DISPATCH_T(u, hipLaunchKernelGGL(dpm_step_kernel<T_>, grid1((size_t)n * HW), dim3(256), 0, st, (float*)pl->x->p, (float*)pl->m1->p, (const float*)pl->F, (T_*)pl->xin, n, C, HW, 8, u->chunk, ks[i], Fg, gscale, gpl ? (T_*)gpl->xin : (T_*)nullptr));
+            TD_DISPATCH_T(u, hipLaunchKernelGGL(dpm_step_kernel<T_>, grid1((size_t)n * HW), dim3(256), 0, st, (float*)pl->x->p, (float*)pl->m1->p, (const float*)pl->F, (T_*)pl->xin, n, C, HW, 8, u->chunk, ks[i], Fg, gscale, gpl ? (T_*)gpl->xin : (T_*)nullptr, solver_order == 3 ? (float*)pl->m2->p : (float*)nullptr));
         }
         HIP_TRY(hipGetLastError());
         return TD_OK;
@@ -1277,7 +1297,7 @@ static int sample_edm_lane(td_unet* u, td_unet* guide, float gscale, int n, int 
         // the guide's plan can be evicted / its buffers re-allocated independently of this plan: key the graph on them too
         const void* gkey = gpl ? (const void*)gpl->cvec->p : nullptr;
         if (!pl->graph || pl->graph_sigmas != sg || pl->graph_sigma_data != sigma_data || pl->graph_solver_order != solver_order ||
-            pl->graph_guide != (const void*)gpl || pl->graph_guide_cvec != gkey || pl->graph_gscale != gscale) {
+            pl->graph_guide != (const void*)gpl || pl->graph_guide_cvec != gkey || pl->graph_gscale != gscale || pl->graph_fuse != (int)e->option("fuse_solver", 1)) {
             pl->drop_graph();
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -1288,7 +1308,7 @@ static int sample_edm_lane(td_unet* u, td_unet* guide, float gscale, int n, int 
             hipError_t ie = hipGraphInstantiate(&pl->graph, g, nullptr, nullptr, 0);
             (void)hipGraphDestroy(g);
             if (ie != hipSuccess) { pl->graph = nullptr; return fail(TD_ERR_HIP, std::string("graph instantiate: ") + hipGetErrorString(ie)); }
-            pl->graph_sigmas = sg; pl->graph_sigma_data = sigma_data; pl->graph_solver_order = solver_order;
+            pl->graph_sigmas = sg; pl->graph_sigma_data = sigma_data; pl->graph_solver_order = solver_order; pl->graph_fuse = (int)e->option("fuse_solver", 1);
             pl->graph_guide = gpl; pl->graph_guide_cvec = gkey; pl->graph_gscale = gscale;
         }
         HIP_TRY(hipGraphLaunch(pl->graph, st));

@@ -201,7 +201,7 @@ __global__ void unpack_output_kernel(const float* __restrict__ F, float* __restr
 template <typename T>
 __global__ void dpm_step_kernel(float* __restrict__ x, float* __restrict__ m1, const float* __restrict__ F, T* __restrict__ xin,
                                 int N, int C, int HW, int fstride, int cstride, SchedCoef k, const float* __restrict__ Fg, float gscale,
-                                T* __restrict__ xin2) {
+                                T* __restrict__ xin2, float* __restrict__ m2) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)N * HW) return;
     int n = (int)(i / HW), p = (int)(i % HW);
@@ -210,15 +210,11 @@ __global__ void dpm_step_kernel(float* __restrict__ x, float* __restrict__ m1, c
         float xs = x[xi];
         float f = F[i * fstride + c];
         if (Fg) { const float g = Fg[i * fstride + c]; f = g + gscale * (f - g); }  // autoguidance (sample_diffusion_base.py:107-110,155-160)
-        float m0 = k.c_skip * xs + k.c_out * f;
-        float xn;
-        if (k.order == 1) {
-            xn = k.a * xs - k.b0 * m0;
-        } else {
-            float d1 = k.inv_r0 * (m0 - m1[xi]);
-            xn = k.a * xs - k.b0 * m0 - (0.5f * k.b0) * d1;
-        }
+        float xn, m0;
+        const float m1v = (k.order == 1 && !m2) ? 0.f : m1[xi];
+        dpm_update(k, xs, f, m1v, k.order == 3 ? m2[xi] : 0.f, xn, m0);
         x[xi] = xn;
+        if (m2) m2[xi] = m1v;   // third-order solver: history shifts m2 <- m1 <- m0
         m1[xi] = m0;
         if (!k.last) {
             xin[i * cstride + c] = (T)(xn * k.c_in_next);
@@ -421,9 +417,9 @@ template __global__ void prep_input_kernel<_Float16>(const float*, _Float16*, in
 template __global__ void write_cond_img_kernel<float>(const float*, float*, int, int, int, int, int);
 template __global__ void write_cond_img_kernel<__bf16>(const float*, __bf16*, int, int, int, int, int);
 template __global__ void write_cond_img_kernel<_Float16>(const float*, _Float16*, int, int, int, int, int);
-template __global__ void dpm_step_kernel<float>(float*, float*, const float*, float*, int, int, int, int, int, SchedCoef, const float*, float, float*);
-template __global__ void dpm_step_kernel<__bf16>(float*, float*, const float*, __bf16*, int, int, int, int, int, SchedCoef, const float*, float, __bf16*);
-template __global__ void dpm_step_kernel<_Float16>(float*, float*, const float*, _Float16*, int, int, int, int, int, SchedCoef, const float*, float, _Float16*);
+template __global__ void dpm_step_kernel<float>(float*, float*, const float*, float*, int, int, int, int, int, SchedCoef, const float*, float, float*, float*);
+template __global__ void dpm_step_kernel<__bf16>(float*, float*, const float*, __bf16*, int, int, int, int, int, SchedCoef, const float*, float, __bf16*, float*);
+template __global__ void dpm_step_kernel<_Float16>(float*, float*, const float*, _Float16*, int, int, int, int, int, SchedCoef, const float*, float, _Float16*, float*);
 template __global__ void consistency_pre_kernel<float>(const float*, const float*, float*, float*, int, int, int, int, float, float, float, int);
 template __global__ void consistency_pre_kernel<__bf16>(const float*, const float*, float*, __bf16*, int, int, int, int, float, float, float, int);
 template __global__ void consistency_pre_kernel<_Float16>(const float*, const float*, float*, _Float16*, int, int, int, int, float, float, float, int);

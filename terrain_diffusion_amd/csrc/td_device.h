@@ -21,7 +21,32 @@ struct ConvSeg {
     float inv_c;          // 1/C_total for the pixel norm
 };
 
-enum { EPI_PLAIN = 0, EPI_EMB_SILU = 1, EPI_RESIDUAL = 2 };
+struct SchedCoef {        // one DPM-Solver++ step, fp32 scalars computed on the host
+    float c_skip, c_out;  // x0 = c_skip*x + c_out*F
+    float a, b0, inv_r0;  // order1: a*x - b0*m0 ; order2: ... - 0.5*b0*inv_r0*(m0-m1)
+    float inv_r1, f01, inv_r01, c1, c2;  // order3 (dpmsolver.py:598-613): D1_0 = inv_r0 (m0-m1), D1_1 = inv_r1 (m1-m2), D1 = D1_0 + f01 (D1_0-D1_1),
+                                         // D2 = inv_r01 (D1_0-D1_1); x = a*x - b0*m0 + c1*D1 - c2*D2
+    float c_in_next;      // next model input scale (0 on the last step)
+    int order;
+    int last;
+};
+
+// One DPM-Solver++ (1st / 2nd order multistep) update of one value: x0 prediction m0 = c_skip x + c_out F, then the exponential-integrator step
+// (dpmsolver.py:245-258, 472-482, 515-540).  Shared by dpm_step_kernel and the fused conv epilogue (EPI_DPM_STEP); the fused multiply-adds are
+// spelled out so that both places round identically (the compiler's own contraction choices differ from context to context).
+__device__ __forceinline__ void dpm_update(const SchedCoef& k, float xs, float f, float m1v, float m2v, float& xn, float& m0) {
+    m0 = __builtin_fmaf(k.c_skip, xs, k.c_out * f);
+    const float base = __builtin_fmaf(k.a, xs, -(k.b0 * m0));
+    if (k.order == 1) xn = base;
+    else if (k.order == 2) xn = __builtin_fmaf(-(0.5f * k.b0), k.inv_r0 * (m0 - m1v), base);
+    else {  // third-order multistep update (dpmsolver.py:563-615)
+        const float d10 = k.inv_r0 * (m0 - m1v), d11 = k.inv_r1 * (m1v - m2v), dd = d10 - d11;
+        const float d1 = __builtin_fmaf(k.f01, dd, d10), d2 = k.inv_r01 * dd;
+        xn = __builtin_fmaf(-k.c2, d2, __builtin_fmaf(k.c1, d1, base));
+    }
+}
+
+enum { EPI_PLAIN = 0, EPI_EMB_SILU = 1, EPI_RESIDUAL = 2, EPI_DPM_STEP = 3 };
 
 struct ConvParams {
     ConvSeg seg[3];
@@ -49,16 +74,18 @@ struct ConvParams {
     void* out2;           // optional second output, same layout as out: mp_silu(out2_scale * out) -- the consumer's activation, done once here
     float out2_scale;
     const void* zeros;    // >= 16 zero bytes in device memory: source of the halo outside the image for LDS-DMA patch staging (conv_pp.hip)
+    // EPI_DPM_STEP (the U-Net's output conv inside the EDM sampler): the DPM-Solver++ update and the next step's input preconditioning run in
+    // this conv's epilogue instead of a separate pass over F (dpmsolver.py:226-258, 454-561, 650-726) -- the conv result is the model output F
+    float* dpm_x;         // sample, planar fp32 [N][Cout][H*W], updated in place
+    float* dpm_m1;        // previous x0 prediction (multistep history), same layout, updated in place
+    float* dpm_m2;        // the one before (third-order solver only), or null
+    void* dpm_xin;        // next step's model input, NHWC T with dpm_xin_cstride elements per pixel: channels [0, Cout) = x_new * c_in_next
+    int dpm_xin_cstride;
+    SchedCoef dpm_k;
     int reverse;          // scheduling hint (speed only, never changes a bit): 1 = logical workgroup ids are walked backwards (the host alternates it
                           // from layer to layer: the producer's last-written, still cached rows are read first)
 };
 
-struct SchedCoef {        // one DPM-Solver++ step, fp32 scalars computed on the host
-    float c_skip, c_out;  // x0 = c_skip*x + c_out*F
-    float a, b0, inv_r0;  // order1: a*x - b0*m0 ; order2: ... - 0.5*b0*inv_r0*(m0-m1)
-    float c_in_next;      // next model input scale (0 on the last step)
-    int order;
-    int last;
-};
+
 
 }  // namespace td

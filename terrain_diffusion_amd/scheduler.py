@@ -22,8 +22,8 @@ class EDMDPMSolverMultistepScheduler:
                  lower_order_final=True, euler_at_final=False, final_sigmas_type="zero", scaling_p=None, scaling_t=0.05, **_ignored):
         if sigma_schedule != "karras" or algorithm_type != "dpmsolver++" or solver_type != "midpoint" or scaling_p is not None:
             raise NotImplementedError("accelerated path covers the released configuration: karras / dpmsolver++ / midpoint")
-        if solver_order not in (1, 2) or prediction_type != "epsilon" or final_sigmas_type != "zero":
-            raise NotImplementedError("solver_order in {1,2}, prediction_type='epsilon', final_sigmas_type='zero'")
+        if solver_order not in (1, 2, 3) or prediction_type != "epsilon" or final_sigmas_type != "zero":
+            raise NotImplementedError("solver_order in {1,2,3}, prediction_type='epsilon', final_sigmas_type='zero'")
         self.config = SimpleNamespace(sigma_min=sigma_min, sigma_max=sigma_max, sigma_data=sigma_data, rho=rho, solver_order=solver_order,
                                       lower_order_final=lower_order_final, euler_at_final=euler_at_final, final_sigmas_type=final_sigmas_type,
                                       prediction_type=prediction_type, num_train_timesteps=num_train_timesteps)
@@ -82,17 +82,27 @@ class EDMDPMSolverMultistepScheduler:
         sig = self.sigmas.to(sample.device)
         final = i == n - 1
         m0 = self.precondition_outputs(sample, model_output, sig[i])
-        m1 = self.model_outputs[-1]
-        self.model_outputs = [m1, m0][-self.config.solver_order:] if self.config.solver_order > 1 else [m0]
+        hist = [m for m in self.model_outputs if m is not None]
+        m1 = hist[-1] if hist else None
+        m2 = hist[-2] if len(hist) > 1 else None
+        self.model_outputs = ([None] * self.config.solver_order + hist + [m0])[-self.config.solver_order:]
         a = sig[i + 1] / sig[i]
         h = -torch.log(sig[i + 1]) + torch.log(sig[i])
         b0 = torch.exp(-h) - 1.0
+        second = i == n - 2 and self.config.lower_order_final and n < 15          # dpmsolver.py:694-696
         if self.config.solver_order == 1 or self.lower_order_nums < 1 or final:
             prev = a * sample - b0 * m0
-        else:
+        elif self.config.solver_order == 2 or self.lower_order_nums < 2 or second:
             h0 = -torch.log(sig[i]) + torch.log(sig[i - 1])
             d1 = (1.0 / (h0 / h)) * (m0 - m1)
             prev = a * sample - b0 * m0 - 0.5 * b0 * d1
+        else:                                                                       # third-order multistep update, dpmsolver.py:563-615
+            h0, h1 = -torch.log(sig[i]) + torch.log(sig[i - 1]), -torch.log(sig[i - 1]) + torch.log(sig[i - 2])
+            r0, r1 = h0 / h, h1 / h
+            d1_0, d1_1 = (1.0 / r0) * (m0 - m1), (1.0 / r1) * (m1 - m2)
+            d1 = d1_0 + (r0 / (r0 + r1)) * (d1_0 - d1_1)
+            d2 = (1.0 / (r0 + r1)) * (d1_0 - d1_1)
+            prev = a * sample - b0 * m0 + ((torch.exp(-h) - 1.0) / h + 1.0) * d1 - ((torch.exp(-h) - 1.0 + h) / h ** 2 - 0.5) * d2
         if self.lower_order_nums < self.config.solver_order:
             self.lower_order_nums += 1
         self._step_index += 1

@@ -189,6 +189,27 @@ def gen_schedule():
     save("schedule", **out)
 
 
+def gen_schedule3():
+    """scheduler traces of the reference with solver_order = 3 (dpmsolver.py:563-615 third-order multistep update, order rule :688-715) and 1."""
+    from terrain_diffusion.scheduler.dpmsolver import EDMDPMSolverMultistepScheduler
+    from oracle import rng
+    out = {}
+    for order in (3, 1):
+        for n in (6, 20):
+            sch = EDMDPMSolverMultistepScheduler(sigma_min=0.002, sigma_max=80.0, sigma_data=0.5, solver_order=order)
+            sch.set_timesteps(n)
+            x = torch.from_numpy(rng.standard_normal(950 + n, (2, 5, 8, 8))) * sch.sigmas[0]
+            trace = []
+            for t, sigma in zip(sch.timesteps, sch.sigmas):
+                xin = sch.precondition_inputs(x, sigma)
+                cn = sch.trigflow_precondition_noise(sigma.view(-1))
+                F_ = torch.tanh(0.3 * xin) - 0.2 * torch.cos(cn)
+                x = sch.step(F_, t, x).prev_sample
+                trace.append(x.numpy().copy())
+            out[f"trace_order{order}_{n}"] = np.stack(trace)
+    save("schedule3", **out)
+
+
 def _ref_model(cfg, sd):
     from terrain_diffusion.models.edm_unet import EDMUnet2D
     m = EDMUnet2D(**cfg)
@@ -522,7 +543,7 @@ def gen_bounded_twins():
     save("bounded_twins", **out)
 
 
-ALL = dict(bounded_twins=gen_bounded_twins, compose=gen_compose, guided=gen_guided, latent_glue=gen_latent_glue, stage_glue=gen_stage_glue, stages=gen_stages, rng=gen_rng, geometry=gen_geometry, schedule=gen_schedule, unet=gen_unet, sampling=gen_sampling)
+ALL = dict(schedule3=gen_schedule3, bounded_twins=gen_bounded_twins, compose=gen_compose, guided=gen_guided, latent_glue=gen_latent_glue, stage_glue=gen_stage_glue, stages=gen_stages, rng=gen_rng, geometry=gen_geometry, schedule=gen_schedule, unet=gen_unet, sampling=gen_sampling)
 
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden generation needs the reference checkout"

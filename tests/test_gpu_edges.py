@@ -278,3 +278,65 @@ def test_pano_denoise_ddim_cfg_step_vs_oracle(td):
     err = rel_rms(got.cpu().numpy(), ref)
     print(f"pano.denoise (4 DDIM steps, CFG 7.5) vs oracle/ddim.py: rel-RMS {err:.2e}")
     assert err < 2e-6
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_solver_step_fused_into_output_conv_is_bit_identical(td, dtype):
+    """north_star: 'the per-tile EDM scheduler step ... fused into the epilogue'.  With engine option fuse_solver (default on) the DPM-Solver++ update
+    and the next step's input preconditioning run in the epilogue of the U-Net's output conv (EPI_DPM_STEP) instead of a separate pass over F;
+    the arithmetic and its order are the separate kernel's, so 12 steps of the tiled sampler agree BIT FOR BIT with fuse_solver = 0 (which the
+    autoguided sampler still uses: its update needs both models' outputs)."""
+    import torch
+    from oracle import tiling
+    from oracle.unet import synth_state_dict, tiny_config
+    from terrain_diffusion_amd.engine import get_engine
+    eng = get_engine("cuda")
+    cfg = tiny_config(64, 1)
+    m = td.EDMUnet2D(**cfg, dtype=dtype).load_state_dict(synth_state_dict(cfg, seed=77))
+    sch = td.EDMDPMSolverMultistepScheduler()
+    cond = tiling.synthetic_cond_grid(4, 2)
+    kw = dict(cond_means=torch.zeros(7), cond_stds=torch.ones(7), noise_level=torch.tensor(0.0), histogram_raw=torch.zeros(1, 5), steps=12, tile_size=16, noise_seed=3)
+    outs = {}
+    try:
+        for f in (1, 0):
+            eng.set_option("fuse_solver", f)
+            outs[f] = td.sample_base_diffusion(m, sch, (1, 5, 40, 24), cond, **kw).clone()
+    finally:
+        eng.set_option("fuse_solver", 1)
+    assert torch.isfinite(outs[1]).all() and torch.equal(outs[1], outs[0])
+    m.close()
+
+
+def test_third_order_solver_on_engine(td):
+    """solver_order = 3 (dpmsolver.py:563-615) through the engine: the tiled sampler in fp32 mode against the oracle's tiled sampler (whose scheduler
+    restatement is pinned to traces of the reference scheduler, tests/golden/schedule3.npz), 6 steps (order trace 1,2,3,3,2,1: lower_order_second)
+    and 16 steps; the fused output-conv epilogue and the separate solver kernel agree bit for bit."""
+    import torch
+    from oracle import tiling
+    from oracle.unet import OracleUnet, synth_state_dict, tiny_config
+    from terrain_diffusion_amd.engine import get_engine
+    eng = get_engine("cuda")
+    cfg = tiny_config(64, 1)
+    sd = synth_state_dict(cfg, seed=77)
+    m = td.EDMUnet2D(**cfg, dtype="fp32").load_state_dict(sd)
+    om = OracleUnet(cfg, sd)
+    sch = td.EDMDPMSolverMultistepScheduler(solver_order=3)
+    cond = tiling.synthetic_cond_grid(3, 3)
+    kw = dict(cond_means=torch.zeros(7), cond_stds=torch.ones(7), noise_level=torch.tensor(0.0), histogram_raw=torch.zeros(1, 5), tile_size=16, noise_seed=11)
+    try:
+        for steps in (6, 16):
+            got = td.sample_base_diffusion(m, sch, (1, 5, 32, 32), cond, steps=steps, **kw).clone()
+            ref = tiling.sample_base_diffusion_tiled(om, (1, 5, 32, 32), cond, steps=steps, tile_size=16, noise_seed=11, solver_order=3)
+            err = rel_rms(got.cpu().numpy(), ref.numpy())
+            print(f"third-order DPM-Solver++, {steps} steps, fp32 engine vs oracle: {err:.2e}")
+            assert err < 1e-5
+            eng.set_option("fuse_solver", 0)
+            unfused = td.sample_base_diffusion(m, sch, (1, 5, 32, 32), cond, steps=steps, **kw)
+            eng.set_option("fuse_solver", 1)
+            assert torch.equal(got, unfused)
+        second = td.sample_base_diffusion(m, td.EDMDPMSolverMultistepScheduler(solver_order=2), (1, 5, 32, 32), cond, steps=16, **kw)
+        assert not torch.equal(second, got)                       # the order really changed the trajectory
+    finally:
+        eng.set_option("fuse_solver", 1)
+        eng.set_option("solver_order", 2)
+    m.close()

@@ -336,3 +336,29 @@ def test_ddim_restatement_invariants():
     assert np.allclose(x, np.float32(acp[0] ** 0.5) * x0 + np.float32((1 - acp[0]) ** 0.5) * eps, atol=2e-5)   # past the last step: alpha = alphas_cumprod[0]
     u, c = rng.standard_normal(73, (1, 4, 8, 8)), rng.standard_normal(74, (1, 4, 8, 8))
     assert np.array_equal(ddim.cfg_mix(u, c, 1.0), u + (c - u)) and np.allclose(ddim.cfg_mix(u, c, 7.5), 7.5 * c - 6.5 * u, atol=1e-5)
+
+
+def test_solver_trace_orders_1_and_3(golden):
+    """solver_order = 3 (third-order multistep update, dpmsolver.py:563-615; order rule :688-715 incl. lower_order_second for N < 15) and 1, against
+    traces of the reference scheduler itself (tests/golden/schedule3.npz): the oracle's explicit-counter restatement AND the product's host-side
+    scheduler.step() (the drop-in surface for callers that drive the loop themselves)."""
+    from terrain_diffusion_amd.scheduler import EDMDPMSolverMultistepScheduler
+    g = golden("schedule3")
+    assert schedule.solver_orders(6, solver_order=3) == [1, 2, 3, 3, 2, 1] and schedule.solver_orders(20, solver_order=3) == [1, 2] + [3] * 17 + [1]
+    for order in (3, 1):
+        for n in (6, 20):
+            sig, _ = schedule.karras_sigmas(n)
+            orders = schedule.solver_orders(n, solver_order=order)
+            x = torch.from_numpy(rng.standard_normal(950 + n, (2, 5, 8, 8))) * sig[0]
+            sch = EDMDPMSolverMultistepScheduler(solver_order=order)
+            sch.set_timesteps(n)
+            xs = x.clone()
+            m1 = m2 = None
+            for i in range(n):
+                F_ = torch.tanh(0.3 * schedule.precondition_inputs(x, sig[i])) - 0.2 * torch.cos(schedule.trigflow_t(sig[i].view(-1)))
+                x, m0 = schedule.dpm_step(sig, i, orders[i], x, F_, m1, m_prev2=m2)
+                m1, m2 = m0, m1
+                assert rel_rms(x.numpy(), g[f"trace_order{order}_{n}"][i]) < 2e-6, (order, n, i)
+                Fs = torch.tanh(0.3 * sch.precondition_inputs(xs, sch.sigmas[i])) - 0.2 * torch.cos(sch.trigflow_precondition_noise(sch.sigmas[i].view(-1)))
+                xs = sch.step(Fs, sch.timesteps[i], xs).prev_sample
+                assert rel_rms(xs.numpy(), g[f"trace_order{order}_{n}"][i]) < 2e-6, ("host scheduler", order, n, i)
