@@ -514,8 +514,12 @@ template <typename T>
 static hipError_t launch_conv_glds_t(const ConvParams& p, bool narrow, int bn, int variant, hipStream_t st) {
     if (bn == 64) {
         if (narrow) return hipErrorInvalidValue;
+        // variant 2 "tiny" (round 3, the latency regime): 4 waves on 64 pixels (4x16) x 64 couts, 32x32 per wave.  A small batch then fills the chip
+        // with (pixel tile, cout tile) workgroups instead of K slices: fewer or no fp32 partial slabs to write, read back and reduce
+        if (variant == 2) return launch_glds_cfg<T, 4, 16, 1, 64, 2, 2>(p, st);
         return variant == 1 ? launch_glds_cfg<T, 8, 16, 1, 64, 4, 1>(p, st) : launch_glds_cfg<T, 16, 16, 1, 64, 8, 1>(p, st);
     }
+    if (variant == 2) return hipErrorInvalidValue;
     if (variant == 1) {
         if (!narrow) return bn == 128 ? launch_glds_cfg<T, 8, 16, 1, 128, 2, 2>(p, st) : launch_glds_cfg<T, 8, 16, 1, 96, 4, 1>(p, st);
         return bn == 128 ? launch_glds_cfg<T, 8, 8, 2, 128, 2, 2>(p, st) : launch_glds_cfg<T, 8, 8, 2, 96, 4, 1>(p, st);

@@ -540,7 +540,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
     // every option the plan builder reads is part of the cache key (a plan built under other options must never be reused)
     static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn", "pp",
                                                "pp_min_items_per_cu", "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
-                                               "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups", "glds_round_aware", "walk_alternate"};
+                                               "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups", "glds_round_aware", "walk_alternate", "glds_tiny"};
     std::string key = std::to_string(N) + "_" + std::to_string(H) + "_" + std::to_string(W);
     for (const char* o : kPlanOptions) key += "_" + std::to_string((long long)u->eng->option(o, -7));
     if (lane) key += "_lane" + std::to_string(lane);   // a second, independent activation set of the same shape (concurrent half-batches)
@@ -654,14 +654,30 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
             }
             if (u->bf16 && bn2 && u->eng->option("glds", 1) && (inv || mt2 * (cw.cout_pad / bn2) >= u->eng->option("glds_min_wgs", 8))) {
                 op.flavor = 2; op.bn = bn2; op.glds_variant = variant;
-                const int TH2 = variant ? 8 : (op.narrow ? 8 : 16), NIMG2 = op.narrow ? (variant ? 2 : 4) : 1;
+                int TH2 = variant ? 8 : (op.narrow ? 8 : 16);
+                const int NIMG2 = op.narrow ? (variant ? 2 : 4) : 1;
                 p.tiles_x = (w + TW2 - 1) / TW2; p.tiles_y = (h + TH2 - 1) / TH2; p.img_groups = (N + NIMG2 - 1) / NIMG2;
                 p.n_ntiles = cw.cout_pad / bn2; p.ksplit = 1;
                 // too few workgroups to give every SIMD two waves (8x8 level of a 64-tile batch, small batches): split K, the fp32
                 // partials are summed in fixed order by conv_splitk_reduce_kernel (not in batch_invariant mode: the K order changes)
                 const int64_t wgs = mt2 * p.n_ntiles, slots = variant ? 512 : 256;
-                if (!inv && use_splitk && u->eng->option("glds_splitk", 1) && kgroups >= u->eng->option("glds_splitk_from_groups", 2) && wgs * 2 <= slots)
+                const bool may_split = !inv && use_splitk && u->eng->option("glds_splitk", 1) && wgs * 2 <= slots;
+                if (may_split && kgroups >= u->eng->option("glds_splitk_from_groups", 2))
                     p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(u->eng->option("glds_splitk_max", 32), kgroups / std::max<int64_t>(1, u->eng->option("glds_splitk_min_groups", 1))), slots / wgs);
+                // Latency regime, 16-wide maps (round 3, option "glds_tiny"): in the split-K regime the fp32 partial slabs dominate the traffic -- at
+                // batch 1 a forward wrote 0.95 GB and read 1.7 GB against 0.5 GB of weights (profiles/r03_batch1_hbm_traffic.json).  A "tiny" tile
+                // (64 px x 64 couts, 4 waves) fills the chip with (pixel tile, cout tile) workgroups instead of K slices: K is split only as far as
+                // it takes to reach ~1.5 workgroups per CU (64x64 level of one tile: no split at all).  tools/b1_tiny.sh: 18 -> 12 us (192->192 at
+                // 64x64), 31 -> 21 us (384->384), 25 -> 19.5 us (768->384 at 32x32) incl. the reduce launch.  Same K order and MFMA per output as
+                // every other shape (bit-identical when neither splits K).
+                if (may_split && !op.narrow && variant == 1 && u->eng->option("glds_tiny", 0) != 0) {
+                    const int64_t wgs_tiny = tiles(4, 1) * (cw.cout_pad / 64);
+                    if (wgs_tiny <= 384) {
+                        op.glds_variant = 2; op.bn = 64; TH2 = 4;
+                        p.tiles_y = (h + TH2 - 1) / TH2; p.n_ntiles = cw.cout_pad / 64;
+                        p.ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(kgroups, u->eng->option("glds_splitk_max", 32)), 384 / wgs_tiny));
+                    }
+                }
                 // persistent ping-pong flavour (conv_pp.hip): 3x3-only convs on >= 16-wide maps whose work items fill the chip at least
                 // "pp_min_items_per_cu" times; bit-identical to the LDS-DMA flavour (same K order, same MFMA), so the choice may depend on the batch
                 bool all9 = true;
@@ -945,7 +961,7 @@ static int run_unet(td_unet* u, Plan& pl, int step, const SchedCoef* fuse = null
             if (p.res) mb_ += (double)p.N * p.res_Hs * p.res_Ws * p.Cout * es_;
             mb_ += (double)p.N * p.H * p.W * p.Cout * (p.out_f32 ? 4.0 : es_) * (p.out2 ? 2.0 : 1.0);
             mb_ *= 1e-6;
-            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f mb%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 3 ? "p" : op.flavor == 2 ? (op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_, mb_); ev_label.push_back(op.label + tag);
+            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f mb%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 3 ? "p" : op.flavor == 2 ? (op.glds_variant == 2 ? "t" : op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_, mb_); ev_label.push_back(op.label + tag);
             double kk = 0; for (int s_ = 0; s_ < p.nseg; ++s_) kk += (double)p.seg[s_].C * p.seg[s_].taps;
             ev_flop.push_back(op.flavor >= 2 ? 2.0 * p.N * p.H * p.W * (double)p.Cout * kk : 0.0); }
         if (e != hipSuccess) return fail(TD_ERR_HIP, "conv launch " + op.label + ": " + hipGetErrorString(e));

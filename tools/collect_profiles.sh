@@ -10,6 +10,10 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "S
   tag=$(echo $c | cut -d' ' -f1)
   timeout 900 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$tag -- $BENCH > $OUT/pmc_$tag.log 2>&1
 done
+B1="python $R/bench.py --workload tiles --tiles-per-step 1 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-latency"
+for c in "FETCH_SIZE" "WRITE_SIZE"; do
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/b1pmc_$c -- $B1 > $OUT/b1pmc_$c.log 2>&1
+done
 python3 - <<'PY'
 import csv, glob, os, json, collections
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); out = R + "/gpurun_out/profiles_new"
@@ -52,7 +56,18 @@ import __graft_entry__ as ge
 import ctypes as C
 _l = C.CDLL(ge.LIB); _l.td_build_id.restype = C.c_char_p
 json.dump({"csrc_sha16": ge.csrc_sha16(), "library_build_id": _l.td_build_id().decode(), "note": "rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-latency` (batch 64 x 20 solver steps per bench step). FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced stream); WRITE_SIZE uncalibrated; units KB -> bytes x1024. mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs).", "kernels": kern}, open(out + "/hbm_traffic_and_mfma_util.json", "w"), indent=1)
+# batch-1 leg: HBM bytes per forward (3 bench steps x 20 forwards of ONE tile), all kernels of the U-Net
+b1 = collections.defaultdict(float)
+for f in glob.glob(out + "/b1pmc_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "td::" in r["Kernel_Name"] or "_ZN2td" in r["Kernel_Name"]: b1[r["Counter_Name"]] += float(r["Counter_Value"])
+if b1:
+    fw = 3 * 20
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --workload tiles --tiles-per-step 1 --steps 2 --warmup 1`: 60 forwards of ONE 64x64 tile; engine kernels only. FETCH_SIZE doubled (gfx950 correction), KB -> bytes.",
+               "forwards": fw, "hbm_read_bytes_per_forward": round(b1.get("FETCH_SIZE", 0) * 1024 * 2 / fw), "hbm_write_bytes_per_forward": round(b1.get("WRITE_SIZE", 0) * 1024 / fw),
+               "algorithmic_weight_bytes_per_forward": 253688037 * 2}, open(out + "/batch1_hbm_traffic.json", "w"), indent=1)
+    print(open(out + "/batch1_hbm_traffic.json").read())
 print(open(out + "/kernel_trace_summary.csv").read()[:1500])
 PY
-rm -rf $OUT/kt $OUT/pmc_*/  # raw traces are large; the summaries are what gets committed
+rm -rf $OUT/kt $OUT/pmc_*/ $OUT/b1pmc_*/  # raw traces are large; the summaries are what gets committed
 ls -la $OUT

@@ -14,6 +14,11 @@
 #include "experiments/conv_ps.hip"
 using namespace td;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+__global__ void __launch_bounds__(256) bench_prefetch_kernel(const uint4* __restrict__ w, size_t n16, uint4* sink) {
+    uint4 acc = {0u, 0u, 0u, 0u};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) { const uint4 v = w[i]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
+    if ((acc.x & acc.y & acc.z & acc.w) == 0xfffffffeu && (acc.x ^ acc.y) == 0x12345678u) sink[threadIdx.x] = acc;
+}
 int main(int argc, char** argv) {
     int N = argc > 1 ? atoi(argv[1]) : 64, H = argc > 2 ? atoi(argv[2]) : 64, W = argc > 3 ? atoi(argv[3]) : 64;
     int Cin = argc > 4 ? atoi(argv[4]) : 192, Cout = argc > 5 ? atoi(argv[5]) : 192, taps = argc > 6 ? atoi(argv[6]) : 9;
@@ -37,7 +42,7 @@ int main(int argc, char** argv) {
     ConvParams p; memset(&p, 0, sizeof p);
     p.nseg = 1; p.seg[0].src = x; p.seg[0].C = Cin; p.seg[0].cstride = Cin; p.seg[0].Hs = H; p.seg[0].Ws = W; p.seg[0].taps = taps; p.seg[0].xform = xform; p.seg[0].scale = 1.f;
     p.wpack = w; p.N = N; p.H = H; p.W = W; p.Cout = Cout; p.CoutPad = Cout; p.kgroups = kgroups; p.ksplit = ksplit; p.partial = partial;
-    bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4 || flavor == 6) ? 4 : 2) : 1; int TH = ((flavor == 2 || flavor == 4 || flavor == 5 || flavor == 6) && !narrow) ? 16 : 8;
+    bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4 || flavor == 6) ? 4 : 2) : 1; int TH = flavor == 8 ? 4 : ((flavor == 2 || flavor == 4 || flavor == 5 || flavor == 6) && !narrow) ? 16 : 8;  // flavor 8 = conv_glds variant 2 (tiny tile)
     p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH; p.img_groups = (N + NIMG - 1) / NIMG; p.n_ntiles = Cout / bn;
     p.epi = epi; p.out = out; p.out_cstride = Cout;
     { void* z; CK(hipMalloc(&z, 4096)); CK(hipMemset(z, 0, 4096)); p.zeros = z; }
@@ -51,7 +56,7 @@ int main(int argc, char** argv) {
     if (getenv("TD_EXTRA_LDS")) g_bench_extra_lds = atoi(getenv("TD_EXTRA_LDS"));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto L = [&](const ConvParams& q) { return flavor >= 6 ? launch_conv_ps(q, 1, narrow, bn, flavor - 6, 256, st) : flavor == 5 ? launch_conv_pp(q, 1, bn, 256, st) : flavor >= 2 ? launch_conv_glds(q, 1, narrow, bn, flavor - 2, st) : launch_conv(q, 1, narrow, bn, flavor, st); };
+    auto L = [&](const ConvParams& q) { return flavor == 8 ? launch_conv_glds(q, 1, narrow, bn, 2, st) : flavor >= 6 ? launch_conv_ps(q, 1, narrow, bn, flavor - 6, 256, st) : flavor == 5 ? launch_conv_pp(q, 1, bn, 256, st) : flavor >= 2 ? launch_conv_glds(q, 1, narrow, bn, flavor - 2, st) : launch_conv(q, 1, narrow, bn, flavor, st); };
     for (int i = 0; i < 4; ++i) CK(L((chain && (i & 1)) ? p2 : p));
     CK(hipStreamSynchronize(st));
     const int reps = 20;
@@ -59,11 +64,21 @@ int main(int argc, char** argv) {
     for (int i = 0; i < reps; ++i) CK(L((chain && (i & 1)) ? p2 : p));
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    if (getenv("TD_COLD")) {  // cold-cache timing: evict L2 + MALL (1 GiB memset) before every launch, time each launch by itself
+        void* fl; const size_t fb = (size_t)1 << 30; CK(hipMalloc(&fl, fb)); float acc = 0.f;
+        const int mode = atoi(getenv("TD_COLD"));   // 2: weights pulled back through the memory-side cache by a prefetch kernel before the timed launch; 3: activations too
+        size_t wbytes = 0; for (int s_ = 0; s_ < p.nseg; ++s_) wbytes += (size_t)(p.seg[s_].C / 64) * p.seg[s_].taps * p.CoutPad * 128;
+        for (int i = 0; i < reps; ++i) { CK(hipMemsetAsync(fl, i, fb, st));
+            if (mode >= 2) hipLaunchKernelGGL(bench_prefetch_kernel, dim3(128), dim3(256), 0, st, (const uint4*)p.wpack, wbytes / 16, (uint4*)fl);
+            if (mode >= 3) hipLaunchKernelGGL(bench_prefetch_kernel, dim3(128), dim3(256), 0, st, (const uint4*)p.seg[0].src, (size_t)M * Cin * 2 / 16, (uint4*)fl);
+            CK(hipEventRecord(e0, st)); CK(L(p)); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); float t; CK(hipEventElapsedTime(&t, e0, e1)); acc += t; }
+        printf("   cold caches (mode %d): %.1f us (hot loop above: %.1f us)\n", mode, acc / reps * 1e3, ms * 1e3); CK(hipFree(fl));
+    }
     double flop = 2.0 * M * Cout * Cin * taps;
     printf("N%d %dx%d Cin%d Cout%d taps%d xform%d bn%d ks%d fl%d epi%d stg%d ch%d : %.1f us  %.1f TFLOP/s (%.1f%% of 2500)  wgs=%d\n", N, H, W, Cin, Cout, taps, xform, bn, ksplit, flavor, epi, stagger, chain, ms * 1e3,
            flop / ms / 1e9, flop / ms / 1e9 / 25.0, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * ksplit);
 #ifndef TD_TRACE
-    if (flavor >= 6) {  // bit-exactness of the persistent-stream flavour against conv_glds with the same tile shape
+    if (flavor >= 6 && flavor < 8) {  // bit-exactness of the persistent-stream flavour against conv_glds with the same tile shape
         std::vector<uint16_t> o5(M * Cout), o2(M * Cout), q5, q2;
         std::vector<float> s5, s2;
         const ConvParams& pp_ = p;
