@@ -24,7 +24,8 @@ namespace td {
 #define TD_TACC(acc, a, b)
 #endif
 
-template <typename T, int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N>
+// DMA1: the instantiation that streams 1x1 segments by LDS-DMA (launch_glds_cfg picks it per launch; the plain instantiation is untouched by it)
+template <typename T, int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N, bool DMA1 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4 < 2 ? 2 : (WAVES_M * WAVES_N + 3) / 4) void conv_glds_kernel(const ConvParams p) {
     typedef typename Half<T>::x8 hx8;
     typedef typename Half<T>::x4 hx4;
@@ -38,6 +39,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
     // the next cout tile (or the slab's tail padding) and are never read
     constexpr int NBI = (BN * 128 + NTHR * 16 - 1) / (NTHR * 16);  // LDS-DMA instructions per thread per weight tile
     constexpr int B_BYTES = NBI * NTHR * 16, RING = 3;
+    // 1x1 segments by LDS-DMA (p.dma1x1): a K-group's 64 channels of the tile's BM pixels, 128-byte rows in MFMA column order, 16-byte slots
+    // XOR-swizzled like the weight rows; NST buffers laid over the (then dead) halo patch, DMA_N pieces per thread and buffer
+    constexpr int STAGE_BYTES = BM * 128, NST = WAVES_M * WAVES_N >= 8 ? 3 : 2, DMA_N = BM * 8 / NTHR;
+    static_assert(BM * 8 % NTHR == 0, "1x1 stage: whole DMA rounds");
     // LDS map: [0, RING*B_BYTES) weight ring | activation patch, PITCH bytes per pixel | s_rn.  The ring comes first so that
     // "slot*B_BYTES + 32-row step" fits the 16-bit ds_read offset field; the patch rows are PADDED to 144 B instead of swizzled:
     // 16 consecutive rows then start at 16 different 16-byte positions of the 256-byte bank window (9 is odd), and a fragment
@@ -290,6 +295,90 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
     }
     int gidx = g0;
     for (int seg = seg_first; seg < p.nseg && gidx < g1; ++seg) {
+        if constexpr (DMA1) if (seg > seg_first && p.seg[seg].taps != 9) {
+            // ---- every remaining segment is 1x1 with no input transform (host contract): their K-groups are streamed by LDS-DMA, NST - 1
+            // groups ahead, one barrier per group and no staging through registers (the register path pays a global-load round trip, a
+            // ds_write pass and two barriers per 64 channels: profiles/r03_conv_1x1_dma.txt)
+            const T* psrc = nullptr; int pseg = seg, pchunk = 0, pn = 1;
+            unsigned poff[DMA_N];
+#define TD_P_BEGIN()                                                                                                  \
+            {                                                                                                         \
+                const ConvSeg& sg_ = p.seg[pseg];                                                                     \
+                psrc = (const T*)sg_.src; pn = sg_.C / CHUNK;                                                         \
+                const int Hs_ = sg_.Hs, Ws_ = sg_.Ws, rs_ = sg_.resample, cs_ = sg_.cstride;                          \
+                _Pragma("unroll") for (int i_ = 0; i_ < DMA_N; ++i_) {                                                \
+                    const int e_ = tid + i_ * NTHR, row_ = e_ >> 3, sl_ = (e_ & 7) ^ TD_SWZ(row_);                    \
+                    int img_, ty_, tx_;                                                                               \
+                    frag_pixel<TW, TPIX>(row_ & ~31, row_ & 31, img_, ty_, tx_);                                      \
+                    const int n_ = n0 + img_, y_ = y0 + ty_, x_ = x0 + tx_;                                           \
+                    /* a pixel outside the image is an MFMA column nobody stores: any readable address will do */     \
+                    const int pix_ = (n_ < p.N && y_ < p.H && x_ < p.W) ? src_pixel(n_, y_, x_, Hs_, Ws_, rs_) : 0;   \
+                    poff[i_] = (unsigned)(pix_ * cs_ + sl_ * PER16) * (unsigned)sizeof(T);                            \
+                }                                                                                                     \
+            }
+#define TD_P_ISSUE(BUF)                                                                                               \
+            {                                                                                                         \
+                const unsigned long long sa_ = (unsigned long long)(psrc + (size_t)pchunk * CHUNK);                   \
+                const unsigned char* su_ = (const unsigned char*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sa_ >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)sa_)); \
+                const unsigned lb_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(ldsw + (unsigned)A_BASE + (unsigned)(BUF) * (unsigned)STAGE_BYTES)); \
+                _Pragma("unroll") for (int i_ = 0; i_ < DMA_N; ++i_) TD_GLDS16(poff[i_], su_, lb_, i_ * NTHR * 16);   \
+                /* past the last group the cursor stays on it: the loop issues unconditionally (fixed vmcnt), the copies are never read */ \
+                if (pchunk + 1 < pn) ++pchunk;                                                                        \
+                else if (pseg + 1 < p.nseg) { ++pseg; pchunk = 0; TD_P_BEGIN(); }                                     \
+            }
+            unsigned xb1[4], xcur[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) xb1[ks] = (unsigned)A_BASE + (unsigned)((wm * WM + l31) * 128 + (((ks * 2 + lh) ^ TD_SWZ(l31)) << 4));
+#define TD_FRAG_READ1(WF, XF, SLOT, KS)                                                                      \
+            {                                                                                                \
+                _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) WF[j_] = *(const u32x4*)(smem + wbase[KS] + ((SLOT) * B_BYTES + j_ * 4096)); \
+                _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_) XF[i_] = *(const u32x4*)(smem + xcur[KS] + i_ * 4096); \
+            }
+#define TD_TAP1D(SLOT)                                                                                       \
+            {                                                                                                \
+                TD_GLDS_B(((SLOT) + 2) % RING);                                                              \
+                TD_FRAG_READ1(wfA_, xfA_, SLOT, 0);                                                          \
+                TD_FRAG_READ1(wfB_, xfB_, SLOT, 1);                                                          \
+                TD_FRAG_MFMA(wfA_, xfA_);                                                                    \
+                TD_FRAG_READ1(wfA_, xfA_, SLOT, 2);                                                          \
+                TD_FRAG_MFMA(wfB_, xfB_);                                                                    \
+                TD_FRAG_READ1(wfB_, xfB_, SLOT, 3);                                                          \
+                TD_FRAG_MFMA(wfA_, xfA_);                                                                    \
+                TD_FRAG_MFMA(wfB_, xfB_);                                                                    \
+            }
+            TD_P_BEGIN();
+            // the builtin (not asm) form is seen by the compiler's wait-count pass: it then knows that no register-path patch load is pending
+            // and does not guard the reuse of those registers with vmcnt waits of its own (which would drain the DMA stream below).
+            // In flight here: the two weight tiles ahead, needed by the first group anyway.
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave is done with the halo patch: the stage buffers take its place
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int d = 0; d < NST - 1; ++d) TD_P_ISSUE(d);
+            int bcur = 0;
+            for (bool first = true; gidx < g1; ++gidx, first = false) {
+                // in flight, oldest first: [W(g), W(g+1) at entry |] S(g) .. S(g+NST-2) interleaved with W(g+1): everything but the youngest
+                // NST-2 stages and (after the first group) the youngest weight tile has to be back
+                if (first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * DMA_N) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * DMA_N + NBI) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();  // stage g and weight tile g are visible; nobody reads stage g-1 / tile g-1 any more
+                asm volatile("" ::: "memory");
+                const int bprev = bcur == 0 ? NST - 1 : bcur - 1;
+                TD_P_ISSUE(bprev);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) xcur[ks] = xb1[ks] + (unsigned)bcur * (unsigned)STAGE_BYTES;
+                if (slot == 0) TD_TAP1D(0) else if (slot == 1) TD_TAP1D(1) else TD_TAP1D(2);
+                slot = slot == 2 ? 0 : slot + 1;
+                bcur = bcur + 1 == NST ? 0 : bcur + 1;
+            }
+#undef TD_TAP1D
+#undef TD_FRAG_READ1
+#undef TD_P_ISSUE
+#undef TD_P_BEGIN
+            break;
+        }
         if (seg > seg_first) {  // first K-group of a later segment: its patch could not be prefetched (different source tensor / transform)
             TD_SEG_BEGIN(seg);
             TD_LOAD_A(0);
@@ -300,7 +389,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
         }
         for (int chunk = (seg == seg_first ? chunk_first : 0); chunk < seg_nchunks && gidx < g1; ++chunk, ++gidx) {
             const bool has_next = chunk + 1 < seg_nchunks && gidx + 1 < g1;
-            if (seg_taps == 9) {  // slot == 0 here: the host orders 3x3 segments before 1x1 segments, and RING divides 9
+            if (DMA1 || seg_taps == 9) {  // slot == 0 here: the host orders 3x3 segments before 1x1 segments, and RING divides 9
                 TD_GROUP_ENTRY();
                 TD_TAPP(0, 0, TD_TOFF(0), TD_TOFF(1)); TD_TAPP(1, 1, TD_TOFF(1), TD_TOFF(2)); TD_TAPP(2, 2, TD_TOFF(2), TD_TOFF(3));
                 TD_TAPP(3, 0, TD_TOFF(3), TD_TOFF(4)); TD_TAPP(4, 1, TD_TOFF(4), TD_TOFF(5)); TD_TAPP(5, 2, TD_TOFF(5), TD_TOFF(6));
@@ -316,7 +405,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
                 TD_ABL_BSTORE(TD_STORE_A());   // visible to the others after the next tap's lgkmcnt(0) + barrier
                 TD_T(tS1_); TD_TACC(tr_stage, tS0_, tS1_);
             }
-            if (seg_taps != 9) {
+            if (!DMA1 && seg_taps != 9) {
                 if (slot == 0) TD_GLDS_B(2) else if (slot == 1) TD_GLDS_B(0) else TD_GLDS_B(1);
                 slot = slot == 2 ? 0 : slot + 1;
             }
@@ -480,20 +569,32 @@ template <typename T, int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N
 static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
     constexpr int NPATCH = NIMG * (TH + 2) * (TW == 8 ? 12 : TW + 2);
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
-    const size_t lds = (size_t)NPATCH * 144 + 3 * (size_t)(((BN * 128 + NTHR * 16 - 1) / (NTHR * 16)) * NTHR * 16) + NPATCH * 4 + (size_t)g_bench_extra_lds;
+    constexpr size_t RING_BYTES = 3 * (size_t)(((BN * 128 + NTHR * 16 - 1) / (NTHR * 16)) * NTHR * 16);
+    constexpr size_t LDS_STAGES = RING_BYTES + (size_t)(WAVES_M * WAVES_N >= 8 ? 3 : 2) * (NIMG * TH * TW * 128);   // 1x1 stage buffers over the patch (+ s_rn)
+    size_t lds = (size_t)NPATCH * 144 + RING_BYTES + NPATCH * 4 + (size_t)g_bench_extra_lds;
     bool seen1 = false;  // the kernel's compile-time ring slots need every 3x3 segment to start on a multiple of 3 K-steps
     for (int s = 0; s < p.nseg; ++s) { if (p.seg[s].taps == 9 && seen1) return hipErrorInvalidValue; if (p.seg[s].taps != 9) seen1 = true; }
+    // LDS-DMA streaming of the 1x1 segments: whole K range in one workgroup, a 3x3 segment first (the ring and the prologue start there), no input
+    // transform on the 1x1 sources, and no pixel-norm table (s_rn lies under the stage buffers)
+    ConvParams pd = p;
+    bool dma = p.dma1x1 != 0 && seen1 && p.ksplit == 1 && p.seg[0].taps == 9 && p.seg[0].xform != 2 && p.res_sumsq == nullptr;
+    for (int s = 0; s < p.nseg && dma; ++s) if (p.seg[s].taps != 9 && p.seg[s].xform != 0) dma = false;
     const int grid = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * p.ksplit;
-    auto kern = conv_glds_kernel<T, TH, TW, NIMG, BN, WAVES_M, WAVES_N>;
+    // the DMA instantiation exists for the 16-wide tiles only (narrow maps reach this size class with split-K, which it does not take)
+    constexpr bool HAS_DMA = TW == 16;
+    if (!HAS_DMA) dma = false;
+    if (dma) lds = std::max(lds, LDS_STAGES + (size_t)g_bench_extra_lds);
+    pd.dma1x1 = dma ? 1 : 0;
+    auto kern = dma ? conv_glds_kernel<T, TH, TW, NIMG, BN, WAVES_M, WAVES_N, HAS_DMA> : conv_glds_kernel<T, TH, TW, NIMG, BN, WAVES_M, WAVES_N, false>;
     // per (instantiation, device): hipFuncSetAttribute applies to the CURRENT device's copy of the kernel only
-    static bool attr_set[64] = {};
+    static bool attr_set[2][64] = {};
     int dev_ = 0; (void)hipGetDevice(&dev_);
-    if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_] || g_bench_extra_lds) {
+    if (dev_ < 0 || dev_ >= 64 || !attr_set[dma][dev_] || g_bench_extra_lds) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;
+        if (dev_ >= 0 && dev_ < 64) attr_set[dma][dev_] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES_M * WAVES_N), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES_M * WAVES_N), lds, st, pd);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && p.ksplit > 1) {
         const size_t W_ = (size_t)p.N * p.H * p.W * ((p.CoutPad + 255) / 256);

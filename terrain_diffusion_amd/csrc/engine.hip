@@ -540,7 +540,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
     // every option the plan builder reads is part of the cache key (a plan built under other options must never be reused)
     static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn", "pp",
                                                "pp_min_items_per_cu", "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
-                                               "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups", "glds_round_aware", "walk_alternate", "glds_tiny"};
+                                               "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups", "glds_round_aware", "walk_alternate", "glds_tiny", "glds_dma1x1"};
     std::string key = std::to_string(N) + "_" + std::to_string(H) + "_" + std::to_string(W);
     for (const char* o : kPlanOptions) key += "_" + std::to_string((long long)u->eng->option(o, -7));
     if (lane) key += "_lane" + std::to_string(lane);   // a second, independent activation set of the same shape (concurrent half-batches)
@@ -731,6 +731,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
         // alternate the walk order of the workgroup grid from conv to conv (option "walk_alternate", speed only): a layer then starts with the
         // rows its producer wrote last, which are still in the 256 MB Infinity Cache (profiles/r03_conv_walk_order_and_stagger.txt)
         if (op.flavor == 2 && u->eng->option("walk_alternate", 1) != 0) p.reverse = (int)(pl.ops.size() & 1);
+        if (op.flavor == 2) p.dma1x1 = u->eng->option("glds_dma1x1", 1) != 0 ? 1 : 0;   // 1x1 segments by LDS-DMA where the launch qualifies (launch_glds_cfg)
         pl.ops.push_back(op);
         return TD_OK;
     };

@@ -84,6 +84,7 @@ struct ConvParams {
     SchedCoef dpm_k;
     int reverse;          // scheduling hint (speed only, never changes a bit): 1 = logical workgroup ids are walked backwards (the host alternates it
                           // from layer to layer: the producer's last-written, still cached rows are read first)
+    int dma1x1;           // conv_glds: stream 1x1 segments by LDS-DMA when the launch qualifies (launch_glds_cfg decides)
 };
 
 
