@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
     const int ksp = bid / mtiles;  // split-K index: this workgroup reduces K-groups [g0, g1) and leaves fp32 partials to the reduce kernel
     const int txi = mtile % p.tiles_x, tyi = (mtile / p.tiles_x) % p.tiles_y, ig = mtile / (p.tiles_x * p.tiles_y);
     const int n0 = ig * NIMG, y0 = tyi * TH, x0 = txi * TW, co0 = ntile * BN;
-    const int g0 = (int)((long)ksp * p.kgroups / p.ksplit), g1 = (int)((long)(ksp + 1) * p.kgroups / p.ksplit);
+    const int g0 = p.kb[ksp], g1 = p.kb[ksp + 1];  // conv_set_kbounds (host)
     int seg_first = 0, chunk_first = 0, kstep_first = 0;  // (segment, chunk) of K-group g0 and the K-step it starts at
     {
         int g = 0;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     const int ksp = bid / mtiles;
     const int txi = mtile % p.tiles_x, tyi = (mtile / p.tiles_x) % p.tiles_y, ig = mtile / (p.tiles_x * p.tiles_y);
     const int n0 = ig * NIMG, y0 = tyi * TH, x0 = txi * TW, co0 = ntile * BN;
-    const int g0 = (int)((long)ksp * p.kgroups / p.ksplit), g1 = (int)((long)(ksp + 1) * p.kgroups / p.ksplit);
+    const int g0 = p.kb[ksp], g1 = p.kb[ksp + 1];  // conv_set_kbounds (host)
 
     // ---- locate the first K group: (segment, chunk) and its first kstep
     int seg = 0, chunk = 0, kstep = 0;

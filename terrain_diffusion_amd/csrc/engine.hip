@@ -540,7 +540,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
     // every option the plan builder reads is part of the cache key (a plan built under other options must never be reused)
     static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn", "pp",
                                                "pp_min_items_per_cu", "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
-                                               "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups", "glds_round_aware", "walk_alternate", "glds_tiny", "glds_dma1x1"};
+                                               "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups", "glds_round_aware", "walk_alternate", "glds_tiny", "glds_dma1x1", "splitk_weighted"};
     std::string key = std::to_string(N) + "_" + std::to_string(H) + "_" + std::to_string(W);
     for (const char* o : kPlanOptions) key += "_" + std::to_string((long long)u->eng->option(o, -7));
     if (lane) key += "_lane" + std::to_string(lane);   // a second, independent activation set of the same shape (concurrent half-batches)
@@ -706,6 +706,8 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
             p.ksplit = 1;
             if (use_splitk && !u->eng->option("batch_invariant", 0) && base < splitk_target / 2 && kgroups > 1) p.ksplit = (int)std::min<int64_t>(kgroups, (splitk_target + base - 1) / base);
         }
+        if (p.ksplit > 64) p.ksplit = 64;
+        if (!conv_set_kbounds(p, u->eng->option("splitk_weighted", 1) != 0, chunk)) return fail(TD_ERR_UNSUPPORTED, "split-K bounds: " + label);
         p.epi = epi; p.out_f32 = out_f32 ? 1 : 0; p.clip = clip; p.zeros = u->eng->zeros;
         // pixel-norm partials of the output: LDS-DMA / ping-pong flavours write one per 32-cout MFMA block (independent of the tile shape),
         // the per-tap flavour one per (cout tile, wave column), the split-K reduce kernel one per 256 couts

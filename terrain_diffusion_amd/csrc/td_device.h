@@ -57,6 +57,7 @@ struct ConvParams {
     int tiles_x, tiles_y, img_groups, n_ntiles;
     int kgroups;          // total (segment, chunk) groups
     int ksplit;           // number of K splits (1 = direct epilogue)
+    unsigned char kb[66]; // split-K slice s reduces K-groups [kb[s], kb[s+1]) (conv_set_kbounds; ksplit <= 64, kgroups <= 255)
     int epi;
     void* out;            // NHWC output (T, or float when out_f32)
     int out_cstride;
@@ -86,6 +87,33 @@ struct ConvParams {
                           // from layer to layer: the producer's last-written, still cached rows are read first)
     int dma1x1;           // conv_glds: stream 1x1 segments by LDS-DMA when the launch qualifies (launch_glds_cfg decides)
 };
+
+// Split-K slice boundaries.  Uniform K-groups: the floor split s*kgroups/ksplit.  A mix of 3x3 and 1x1 groups (the decoder's conv_res1: 3x3 conv
+// + 1x1 skip conv in one launch) is split by K-STEPS (a 3x3 group is 9 of them, a 1x1 group 1) when `weighted`: an even count of groups would give
+// one slice nearly all of the work (12 3x3 + 6 1x1 groups | 18 1x1 groups = 114 | 18 steps).  Every slice keeps at least one group.
+inline bool conv_set_kbounds(ConvParams& p, bool weighted, int chunk = 64) {
+    if (p.ksplit < 1 || p.ksplit > 64 || p.kgroups > 255 || p.ksplit > p.kgroups) return false;
+    int wt[256], n = 0, total = 0; bool mixed = false;
+    for (int s = 0; s < p.nseg; ++s)
+        for (int c = 0; c < p.seg[s].C / chunk && n < 256; ++c) { wt[n] = p.seg[s].taps; mixed = mixed || wt[n] != wt[0]; total += wt[n]; ++n; }
+    if (n != p.kgroups) return false;
+    p.kb[0] = 0; p.kb[p.ksplit] = (unsigned char)n;
+    int g = 0, acc = 0;
+    for (int s = 1; s < p.ksplit; ++s) {
+        int b;
+        if (!(weighted && mixed)) b = (int)((long)s * n / p.ksplit);
+        else {
+            const long target = (long)s * total;   // in units of 1/ksplit K-steps
+            while (g < n && 2 * ((long)acc * p.ksplit - target) + (long)wt[g] * p.ksplit <= 0) { acc += wt[g]; ++g; }   // nearest prefix to the target
+            b = g;
+        }
+        b = b < p.kb[s - 1] + 1 ? p.kb[s - 1] + 1 : b;
+        b = b > n - (p.ksplit - s) ? n - (p.ksplit - s) : b;
+        p.kb[s] = (unsigned char)b;
+        if (weighted && mixed) { while (g < b) { acc += wt[g]; ++g; } }
+    }
+    return true;
+}
 
 
 

@@ -81,7 +81,7 @@ def _forward_with(eng, m, x, t, c, n, **opts):
     try:
         for k, v in opts.items():
             eng.set_option(k, v)
-            prev[k] = {"glds_variant": -1, "glds_bn": 0, "pp": 0, "glds_splitk": 1}[k]
+            prev[k] = {"glds_variant": -1, "glds_bn": 0, "pp": 0, "glds_splitk": 1, "glds_dma1x1": 1}[k]
         eng.set_option("profile", 1)
         eng.profile_read(reset=True)
         y = m(x, t, [c])
@@ -112,7 +112,10 @@ def test_conv_tile_variants_bit_identical(td, base, n):
     t = torch.full((n,), 0.7)
     arms = {"auto": dict(glds_splitk=0), "big": dict(glds_splitk=0, glds_variant=0), "small": dict(glds_splitk=0, glds_variant=1),
             "big/bn96": dict(glds_splitk=0, glds_variant=0, glds_bn=96), "small/bn128": dict(glds_splitk=0, glds_variant=1, glds_bn=128),
-            "pingpong": dict(glds_splitk=0, pp=2)}
+            "pingpong": dict(glds_splitk=0, pp=2),
+            # round 3: 1x1 K-segments (the decoder's fused skip convs) are streamed by LDS-DMA; the register-staged path is the other arm
+            "reg1x1": dict(glds_splitk=0, glds_dma1x1=0), "reg1x1/big": dict(glds_splitk=0, glds_dma1x1=0, glds_variant=0),
+            "reg1x1/small/bn128": dict(glds_splitk=0, glds_dma1x1=0, glds_variant=1, glds_bn=128)}
     res = {k: _forward_with(eng, m, x, t, c, n, **o) for k, o in arms.items()}
     seen = {k: {tag for l in res[k][2] for tag in (" f2b ", " f2s ", " f3p ", "bn96", "bn128") if tag in l} for k in res}
     assert " f2b " in seen["big"] and " f2s " in seen["small"] and " f3p " in seen["pingpong"], seen

@@ -51,6 +51,7 @@ int main(int argc, char** argv) {
         p.res = r; p.res_cstride = Cout; p.res_Hs = H; p.res_Ws = W; p.res_scale = 0.9f; p.clip = 256.f; p.out_sumsq = ssq; }
     (void)stagger;  // round-3 stagger experiments are recorded in profiles/r03_conv_walk_order_and_stagger.txt; the hook is gone from the kernel
     if (want_out2) { void* o2; CK(hipMalloc(&o2, M * Cout * 2)); p.out2 = o2; p.out2_scale = 1.f; }
+    if (!conv_set_kbounds(p, true)) { printf("bad split-K\n"); return 1; }
     ConvParams p2 = p;
     if (chain) { if (Cin != Cout) { printf("chain needs Cin == Cout\n"); return 1; } p2.seg[0].src = out; p2.out = x; p2.reverse = chain == 2 ? 1 : 0; }
     if (getenv("TD_EXTRA_LDS")) g_bench_extra_lds = atoi(getenv("TD_EXTRA_LDS"));
