@@ -129,6 +129,35 @@ def test_conv_tile_variants_bit_identical(td, base, n):
         assert torch.equal(y, y0), (k, float((y - y0).abs().max()))
 
 
+@pytest.mark.parametrize("n,hw", [(20, 72), (7, 40)])
+def test_conv_1x1_dma_ragged_tiles_bit_identical_and_vs_oracle(td, base, n, hw):
+    """the LDS-DMA 1x1 path on maps that do not divide into tiles (72 -> 36 -> 18 -> 9, 40 -> 20 -> 10 -> 5: ragged 16-wide tiles; their out-of-image
+    MFMA columns are fed from a clamped address): bit-identical to the register path, and sample 0 against the oracle (bf16 bound)."""
+    from terrain_diffusion_amd.engine import get_engine
+    from oracle import rng
+    m, om = base
+    eng = get_engine("cuda")
+    x = torch.from_numpy(rng.standard_normal(31, (n, 5, hw, hw))).cuda()
+    c = torch.from_numpy(rng.standard_normal(32, (n, 58))).cuda()
+    t = torch.full((n,), 0.9)
+    ys = {}
+    try:
+        for o in (0, 1):
+            eng.set_option("glds_splitk", 0); eng.set_option("glds_dma1x1", o)
+            eng.set_option("profile", 1); eng.profile_read(reset=True)
+            ys[o] = m(x, t, [c]).clone()
+            labels = [l for l, _, _ in eng.profile_ops()]
+            eng.profile_read(reset=True); eng.set_option("profile", 0)
+            assert any(" f2" in l and "conv_res1" in l and l.startswith("dec.") for l in labels), labels[:5]
+    finally:
+        eng.set_option("glds_splitk", 1); eng.set_option("glds_dma1x1", 1); eng.set_option("profile", 0)
+    assert torch.equal(ys[0], ys[1]), float((ys[0] - ys[1]).abs().max())
+    with torch.no_grad():
+        ref = om(x[:1].cpu(), t[:1], [c[:1].cpu()])
+    err = rel_rms(ys[1][0].cpu().numpy(), ref[0].numpy())
+    assert err < 2e-2, err
+
+
 def _oracle_windows(om, noise, cond, steps, sigma_data=0.5):
     """oracle EDM loop (sample_diffusion_base.py:147-162 restated in oracle/tiling.py) on a batch of windows: returns the pre-blend x."""
     from oracle import schedule
