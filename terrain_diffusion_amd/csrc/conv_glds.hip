@@ -165,8 +165,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
             }                                                                                          \
         }                                                                                              \
     }
-    TD_SEG_BEGIN(seg_first);
-    TD_LOAD_A(chunk_first);
+    // DMA instantiation, K range starting in a 1x1 segment (a pure 1x1 conv, or a later split-K slice): nothing is staged through registers
+    const bool dma_first = DMA1 && p.seg[seg_first].taps != 9;
+    if (!dma_first) {
+        TD_SEG_BEGIN(seg_first);
+        TD_LOAD_A(chunk_first);
+    }
 
     // ---- per-pixel 1/(eps + rms) of the pixel-normed source, for the patch pixels
     const float* rn_sumsq = nullptr; int rn_parts = 0, rn_Hs = 0, rn_Ws = 0, rn_res = 0; float rn_invc = 0.f;
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     __syncthreads();  // s_rn visible (prologue only: this one may drain the two weight tiles, they are needed next anyway)
-    TD_STORE_A();
+    if (!dma_first) TD_STORE_A();
     TD_T(tr_pro);
 
 #define TD_TOFF(T) ((((T) / 3) * PW + ((T) % 3)) * PITCH)
@@ -295,11 +299,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
     }
     int gidx = g0;
     for (int seg = seg_first; seg < p.nseg && gidx < g1; ++seg) {
-        if constexpr (DMA1) if (seg > seg_first && p.seg[seg].taps != 9) {
+        if constexpr (DMA1) if (p.seg[seg].taps != 9) {
             // ---- every remaining segment is 1x1 with no input transform (host contract): their K-groups are streamed by LDS-DMA, NST - 1
             // groups ahead, one barrier per group and no staging through registers (the register path pays a global-load round trip, a
             // ds_write pass and two barriers per 64 channels: profiles/r03_conv_1x1_dma.txt)
-            const T* psrc = nullptr; int pseg = seg, pchunk = 0, pn = 1;
+            const T* psrc = nullptr; int pseg = seg, pchunk = seg == seg_first ? chunk_first : 0, pn = 1;   // a split-K slice may start inside a 1x1 segment
             unsigned poff[DMA_N];
 #define TD_P_BEGIN()                                                                                                  \
             {                                                                                                         \
@@ -574,15 +578,13 @@ static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
     size_t lds = (size_t)NPATCH * 144 + RING_BYTES + NPATCH * 4 + (size_t)g_bench_extra_lds;
     bool seen1 = false;  // the kernel's compile-time ring slots need every 3x3 segment to start on a multiple of 3 K-steps
     for (int s = 0; s < p.nseg; ++s) { if (p.seg[s].taps == 9 && seen1) return hipErrorInvalidValue; if (p.seg[s].taps != 9) seen1 = true; }
-    // LDS-DMA streaming of the 1x1 segments: whole K range in one workgroup, a 3x3 segment first (the ring and the prologue start there), no input
-    // transform on the 1x1 sources, and no pixel-norm table (s_rn lies under the stage buffers)
+    // LDS-DMA streaming of the 1x1 segments (pure 1x1 convs and split-K slices that start inside a 1x1 segment included): no input transform on
+    // the 1x1 sources, and no pixel-norm table (s_rn lies under the stage buffers)
     ConvParams pd = p;
-    bool dma = p.dma1x1 != 0 && seen1 && p.ksplit == 1 && p.seg[0].taps == 9 && p.seg[0].xform != 2 && p.res_sumsq == nullptr;
+    bool dma = p.dma1x1 != 0 && seen1 && p.seg[0].xform != 2 && p.res_sumsq == nullptr;
     for (int s = 0; s < p.nseg && dma; ++s) if (p.seg[s].taps != 9 && p.seg[s].xform != 0) dma = false;
     const int grid = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * p.ksplit;
-    // the DMA instantiation exists for the 16-wide tiles only (narrow maps reach this size class with split-K, which it does not take)
-    constexpr bool HAS_DMA = TW == 16;
-    if (!HAS_DMA) dma = false;
+    constexpr bool HAS_DMA = true;
     if (dma) lds = std::max(lds, LDS_STAGES + (size_t)g_bench_extra_lds);
     pd.dma1x1 = dma ? 1 : 0;
     auto kern = dma ? conv_glds_kernel<T, TH, TW, NIMG, BN, WAVES_M, WAVES_N, HAS_DMA> : conv_glds_kernel<T, TH, TW, NIMG, BN, WAVES_M, WAVES_N, false>;

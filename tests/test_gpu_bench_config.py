@@ -129,10 +129,11 @@ def test_conv_tile_variants_bit_identical(td, base, n):
         assert torch.equal(y, y0), (k, float((y - y0).abs().max()))
 
 
-@pytest.mark.parametrize("n,hw", [(20, 72), (7, 40)])
-def test_conv_1x1_dma_ragged_tiles_bit_identical_and_vs_oracle(td, base, n, hw):
+@pytest.mark.parametrize("n,hw,splitk", [(20, 72, 0), (7, 40, 0), (3, 64, 1), (1, 64, 1)])
+def test_conv_1x1_dma_ragged_tiles_bit_identical_and_vs_oracle(td, base, n, hw, splitk):
     """the LDS-DMA 1x1 path on maps that do not divide into tiles (72 -> 36 -> 18 -> 9, 40 -> 20 -> 10 -> 5: ragged 16-wide tiles; their out-of-image
-    MFMA columns are fed from a clamped address): bit-identical to the register path, and sample 0 against the oracle (bf16 bound)."""
+    MFMA columns are fed from a clamped address), and with split-K on at small batches (slices that start inside a 1x1 segment, narrow 8-wide tiles,
+    pure 1x1 convs): bit-identical to the register path, and sample 0 against the oracle (bf16 bound)."""
     from terrain_diffusion_amd.engine import get_engine
     from oracle import rng
     m, om = base
@@ -143,7 +144,7 @@ def test_conv_1x1_dma_ragged_tiles_bit_identical_and_vs_oracle(td, base, n, hw):
     ys = {}
     try:
         for o in (0, 1):
-            eng.set_option("glds_splitk", 0); eng.set_option("glds_dma1x1", o)
+            eng.set_option("glds_splitk", splitk); eng.set_option("glds_dma1x1", o)
             eng.set_option("profile", 1); eng.profile_read(reset=True)
             ys[o] = m(x, t, [c]).clone()
             labels = [l for l, _, _ in eng.profile_ops()]

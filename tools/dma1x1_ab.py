@@ -9,7 +9,7 @@ from oracle import rng
 eng = td.engine.get_engine("cuda")
 cfg = dict(BASE_CONFIG)
 m = td.EDMUnet2D(**cfg, dtype="bf16").load_state_dict(synth_state_dict(cfg, seed=1234))
-for n in (64, 16, 3):
+for n in (64, 16, 3, 1):
     x = torch.from_numpy(rng.standard_normal(7, (n, 5, 64, 64))).cuda()
     c = torch.from_numpy(rng.standard_normal(8, (n, 58))).cuda()
     t = torch.full((n,), 1.1)
