@@ -733,7 +733,9 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
         // alternate the walk order of the workgroup grid from conv to conv (option "walk_alternate", speed only): a layer then starts with the
         // rows its producer wrote last, which are still in the 256 MB Infinity Cache (profiles/r03_conv_walk_order_and_stagger.txt)
         if (op.flavor == 2 && u->eng->option("walk_alternate", 1) != 0) p.reverse = (int)(pl.ops.size() & 1);
-        if (op.flavor == 2) p.dma1x1 = u->eng->option("glds_dma1x1", 1) != 0 ? 1 : 0;   // 1x1 segments by LDS-DMA where the launch qualifies (launch_glds_cfg)
+        // 1x1 segments by LDS-DMA where the launch qualifies (launch_glds_cfg).  Split-K slices of one or two K-groups (batch 1) do not amortise the
+        // stream's start-up (a barrier and one exposed round trip): measured -0.5 % there, -19 % with 18 groups per slice (8x8 level at batch 64)
+        if (op.flavor == 2) p.dma1x1 = (u->eng->option("glds_dma1x1", 1) != 0 && (p.ksplit == 1 || p.kgroups >= 4 * p.ksplit)) ? 1 : 0;
         pl.ops.push_back(op);
         return TD_OK;
     };

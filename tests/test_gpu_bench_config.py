@@ -129,7 +129,7 @@ def test_conv_tile_variants_bit_identical(td, base, n):
         assert torch.equal(y, y0), (k, float((y - y0).abs().max()))
 
 
-@pytest.mark.parametrize("n,hw,splitk", [(20, 72, 0), (7, 40, 0), (3, 64, 1), (1, 64, 1)])
+@pytest.mark.parametrize("n,hw,splitk", [(20, 72, 0), (7, 40, 0), (64, 64, 1), (3, 64, 1), (1, 64, 1)])
 def test_conv_1x1_dma_ragged_tiles_bit_identical_and_vs_oracle(td, base, n, hw, splitk):
     """the LDS-DMA 1x1 path on maps that do not divide into tiles (72 -> 36 -> 18 -> 9, 40 -> 20 -> 10 -> 5: ragged 16-wide tiles; their out-of-image
     MFMA columns are fed from a clamped address), and with split-K on at small batches (slices that start inside a 1x1 segment, narrow 8-wide tiles,
