@@ -117,6 +117,17 @@ class WorldPipeline:
                 model.save_pretrained(os.path.join(save_directory, folder), **kwargs)
 
     def to(self, device):
+        """world_pipeline.py:568-585 moves the three torch modules.  Here the models live in the engine of the GPU the pipeline was constructed
+        on (weights packed for its kernels at load time): `to` of that device is a no-op, anything else is refused loudly instead of being
+        silently ignored -- construct the pipeline with `device=` (one process per GPU, parallel.shard_requests) to use another GPU."""
+        if isinstance(device, (torch.dtype,)):
+            raise TypeError("WorldPipeline.to(dtype): the storage type is fixed at construction (dtype='bf16' | 'fp16' | 'fp32')")
+        d = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+        if d.type != "cuda":
+            raise RuntimeError(f"WorldPipeline.to({device!r}): terrain_diffusion_amd runs on MI355X only, there is no CPU path")
+        if d.index is not None and d.index != self.engine.device_id:
+            raise RuntimeError(f"WorldPipeline.to({device!r}): this pipeline's models are resident on cuda:{self.engine.device_id}; "
+                               "construct a pipeline with device=... for another GPU")
         return self
 
     # ------------------------------------------------------------------ bind / rebuild (world_pipeline.py:588-740)

@@ -169,6 +169,19 @@ def test_device_window_tensor_integer_indices_drop_their_dimension(td, models):
     w.close()
 
 
+def test_world_pipeline_to_is_loud(td, models):
+    """Round-2 review: `to()` silently ignored its argument.  The resident device is accepted, everything else is refused."""
+    w = _world(td, models)
+    assert w.to("cuda") is w and w.to(torch.device("cuda", 0)) is w and w.to(0) is w
+    with pytest.raises(RuntimeError):
+        w.to("cpu")
+    with pytest.raises(RuntimeError):
+        w.to("cuda:5")
+    with pytest.raises(TypeError):
+        w.to(torch.float16)
+    w.close()
+
+
 def _world_indirect(td, models, path):
     return td.WorldPipeline.from_models(*models, seed=4242, decoder_tile_size=64, decoder_tile_stride=48, latents_batch_size=16,
                                         caching_strategy="indirect").bind(path)
