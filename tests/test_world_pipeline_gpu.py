@@ -182,6 +182,17 @@ def test_world_pipeline_to_is_loud(td, models):
     w.close()
 
 
+def test_measure_latency_harness_on_a_given_world(td, models):
+    """evaluation/latency.py:19-127 twin: drives to() / bind('TEMP') / get(with_climate=False) / empty_cache() / close() the way the reference's
+    harness does and returns its result keys; the second tile must not be slower than a cold one on average over a few runs."""
+    from terrain_diffusion_amd.latency import measure_latency
+    w = td.WorldPipeline.from_models(*models, seed=77, decoder_tile_size=64, decoder_tile_stride=48, latents_batch_size=[1, 2, 4, 8, 16], cache_limit=None)
+    r = measure_latency(world=w, num_runs=3, tile_size=128)
+    for k in ("ttft_mean", "ttst_mean", "ttft_std", "ttst_std", "ttft_p5", "ttft_p50", "ttft_p95", "ttst_p5", "ttst_p50", "ttst_p95", "peak_vram_mb"):
+        assert k in r and r[k] >= 0.0, k
+    assert 0.0 < r["ttst_mean"] <= r["ttft_mean"] * 1.5, r
+
+
 def _world_indirect(td, models, path):
     return td.WorldPipeline.from_models(*models, seed=4242, decoder_tile_size=64, decoder_tile_stride=48, latents_batch_size=16,
                                         caching_strategy="indirect").bind(path)
