@@ -199,3 +199,49 @@ def test_extended_plan_and_request_sharding():
         ys = [b[0] for _, b in part]; xs = [b[1] for _, b in part]
         assert (max(ys) - min(ys)) * (max(xs) - min(xs)) <= 4 * 1024 * 4 * 1024   # a rank's share is spatially compact (Z-curve order)
     assert sorted(seen) == list(range(len(boxes)))
+
+
+def test_shard_plan_properties_random_geometries():
+    """Property test (hypothesis) of the static sharding plan on random canvases, window sizes, strides and world sizes, for both region kinds:
+    every window has exactly one owner; owned regions tile the canvas (extended ones contain their windows); a rank needs exactly the windows
+    that touch its region; what it does not own it is sent by the owner, once, and nothing else is sent; the total seam traffic is symmetric in
+    the sense that matters for the p2p exchange (every (src, dst) list is non-empty and disjoint from dst's own windows)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=120, deadline=None)
+    @given(size=st.sampled_from([8, 16, 32, 64]), frac=st.sampled_from([2, 4]), hm=st.integers(0, 9), wm=st.integers(0, 9), hr=st.integers(0, 7),
+           wr=st.integers(0, 7), world=st.integers(1, 8), extended=st.booleans())
+    def check(size, frac, hm, wm, hr, wr, world, extended):
+        stride = size - size // frac                     # 1/2 or 3/4 of the window
+        H, W = size + hm * stride + hr, size + wm * stride + wr
+        from terrain_diffusion_amd.geometry import tile_starts
+        nr, nc = len(tile_starts(H, size, stride)), len(tile_starts(W, size, stride))
+        try:
+            mesh_shape(world, nr, nc)
+        except ValueError:
+            with pytest.raises(ValueError):
+                ShardPlan(H, W, size, world, stride=stride, extended=extended)
+            return
+        p = ShardPlan(H, W, size, world, stride=stride, extended=extended)
+        allw = [(i, j) for i in range(nr) for j in range(nc)]
+        assert sorted(w for r in range(world) for w in p.windows[r]) == allw and all(p.owner[w] == r for r in range(world) for w in p.windows[r])
+        assert all(len(p.windows[r]) > 0 for r in range(world))
+        if not extended:
+            cover = np.zeros((H, W), dtype=np.int32)
+            for (y0, y1, x0, x1) in p.regions:
+                cover[y0:y1, x0:x1] += 1
+            assert (cover == 1).all()
+        for r, (y0, y1, x0, x1) in enumerate(p.regions):
+            assert 0 <= y0 < y1 <= H and 0 <= x0 < x1 <= W
+            touching = [(i, j) for (i, j) in allw if p.h_starts[i] < y1 and p.h_starts[i] + size > y0 and p.w_starts[j] < x1 and p.w_starts[j] + size > x0]
+            assert sorted(p.needed[r]) == touching
+            if extended:
+                assert all(y0 <= p.h_starts[i] and min(p.h_starts[i] + size, H) <= y1 and x0 <= p.w_starts[j] and min(p.w_starts[j] + size, W) <= x1 for i, j in p.windows[r])
+            got = [w for w in p.needed[r] if p.owner[w] == r]
+            for (s, d), wins in p.sends.items():
+                if d == r:
+                    assert wins and all(p.owner[w] == s and s != r for w in wins)
+                    got += wins
+            assert sorted(got) == touching                     # own + received = needed, nothing twice, nothing missing
+        assert all(s != d and 0 <= s < world and 0 <= d < world for s, d in p.sends)
+    check()
