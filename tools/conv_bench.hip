@@ -27,6 +27,11 @@ int main(int argc, char** argv) {
     const int chunk = 64;
     size_t M = (size_t)N * H * W;
     int kgroups = Cin / chunk, ksteps = kgroups * taps;
+    // TD_SEG2="Cin2,taps2": a second K-segment with its own source tensor (e.g. the decoder's fused 1x1 skip conv: TD_SEG2=576,1); TD_DMA1X1=0|1 picks
+    // the register-staged or the LDS-DMA path for 1x1 segments (conv_glds flavours), and both are compared bit for bit after the timing
+    int Cin2 = 0, taps2 = 1;
+    if (getenv("TD_SEG2")) { if (sscanf(getenv("TD_SEG2"), "%d,%d", &Cin2, &taps2) != 2 || Cin2 % chunk || (taps2 != 1 && taps2 != 9)) { printf("bad TD_SEG2\n"); return 1; } }
+    kgroups += Cin2 / chunk; ksteps += Cin2 / chunk * taps2;
     void *x, *w, *out; float* partial = nullptr;
     CK(hipMalloc(&x, M * Cin * 2)); CK(hipMalloc(&w, (size_t)(ksteps + 2) * Cout * 128 + 16384)); CK(hipMalloc(&out, M * Cout * 2));
     std::vector<uint16_t> hx(M * Cin), hw((size_t)ksteps * Cout * 64);
@@ -42,6 +47,13 @@ int main(int argc, char** argv) {
     ConvParams p; memset(&p, 0, sizeof p);
     p.nseg = 1; p.seg[0].src = x; p.seg[0].C = Cin; p.seg[0].cstride = Cin; p.seg[0].Hs = H; p.seg[0].Ws = W; p.seg[0].taps = taps; p.seg[0].xform = xform; p.seg[0].scale = 1.f;
     p.wpack = w; p.N = N; p.H = H; p.W = W; p.Cout = Cout; p.CoutPad = Cout; p.kgroups = kgroups; p.ksplit = ksplit; p.partial = partial;
+    if (Cin2) {
+        void* x2; CK(hipMalloc(&x2, M * Cin2 * 2));
+        std::vector<uint16_t> hx2(M * Cin2); for (auto& v : hx2) v = 0x3f00 + (rand() & 0xff) + ((rand() & 1) << 15);
+        CK(hipMemcpy(x2, hx2.data(), hx2.size() * 2, hipMemcpyHostToDevice));
+        p.nseg = 2; p.seg[1].src = x2; p.seg[1].C = Cin2; p.seg[1].cstride = Cin2; p.seg[1].Hs = H; p.seg[1].Ws = W; p.seg[1].taps = taps2; p.seg[1].xform = 0; p.seg[1].scale = 1.f;
+    }
+    p.dma1x1 = getenv("TD_DMA1X1") ? atoi(getenv("TD_DMA1X1")) : 1;
     bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4 || flavor == 6) ? 4 : 2) : 1; int TH = flavor == 8 ? 4 : ((flavor == 2 || flavor == 4 || flavor == 5 || flavor == 6) && !narrow) ? 16 : 8;  // flavor 8 = conv_glds variant 2 (tiny tile)
     p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH; p.img_groups = (N + NIMG - 1) / NIMG; p.n_ntiles = Cout / bn;
     p.epi = epi; p.out = out; p.out_cstride = Cout;
@@ -75,7 +87,7 @@ int main(int argc, char** argv) {
             CK(hipEventRecord(e0, st)); CK(L(p)); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); float t; CK(hipEventElapsedTime(&t, e0, e1)); acc += t; }
         printf("   cold caches (mode %d): %.1f us (hot loop above: %.1f us)\n", mode, acc / reps * 1e3, ms * 1e3); CK(hipFree(fl));
     }
-    double flop = 2.0 * M * Cout * Cin * taps;
+    double flop = 2.0 * M * Cout * ((double)Cin * taps + (double)Cin2 * taps2);
     printf("N%d %dx%d Cin%d Cout%d taps%d xform%d bn%d ks%d fl%d epi%d stg%d ch%d : %.1f us  %.1f TFLOP/s (%.1f%% of 2500)  wgs=%d\n", N, H, W, Cin, Cout, taps, xform, bn, ksplit, flavor, epi, stagger, chain, ms * 1e3,
            flop / ms / 1e9, flop / ms / 1e9 / 25.0, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * ksplit);
 #ifndef TD_TRACE
@@ -100,6 +112,17 @@ int main(int argc, char** argv) {
         printf("  check vs conv_glds: %zu / %zu outputs differ (first at %zu: pixel %zu cout %zu), out2 diffs %zu, sumsq diffs %zu, nonzero outputs %zu\n", bad, o5.size(), first, first / Cout, first % Cout, badq, bads, nz);
     }
 #endif
+    if (Cin2 && (flavor == 2 || flavor == 3 || flavor == 8)) {  // register-staged vs LDS-DMA 1x1 path of conv_glds: same K order, same MFMA -> same bits
+        std::vector<uint16_t> o0(M * Cout), o1(M * Cout);
+        for (int d = 0; d < 2; ++d) {
+            ConvParams q = p; q.dma1x1 = d;
+            CK(hipMemset(out, 0, M * Cout * 2));
+            CK(L(q)); CK(hipStreamSynchronize(st));
+            CK(hipMemcpy((d ? o1 : o0).data(), out, o0.size() * 2, hipMemcpyDeviceToHost));
+        }
+        size_t bad = 0, nz = 0; for (size_t i = 0; i < o0.size(); ++i) { bad += o0[i] != o1[i]; nz += (o1[i] & 0x7fff) != 0; }
+        printf("  check dma1x1 1 vs 0: %zu / %zu outputs differ, nonzero outputs %zu%s\n", bad, o0.size(), nz, ksplit > 1 ? "  (split-K: `out` is written by the reduce launch)" : "");
+    }
     if (flavor == 5) {  // bit-exactness of the persistent ping-pong flavour against the LDS-DMA flavour (same K order, same MFMA)
         std::vector<uint16_t> o5(M * Cout), o2(M * Cout);
         CK(hipMemset(out, 0, M * Cout * 2));
