@@ -18,6 +18,7 @@
 #include "conv_igemm.hip"
 #include "conv_glds.hip"
 #include "conv_pp.hip"
+#include "conv_sb.hip"
 #include "small_kernels.hip"
 #include "compose_kernels.hip"
 #include "attn_mfma.hip"
@@ -185,6 +186,8 @@ struct ConvWeights {
     int cout = 0, cout_pad = 0;
     Buf packed;
     int ksteps = 0;
+    Buf packed_sb;             // 16-bit modes: the same weights in MFMA-fragment order for the small-batch flavour (conv_sb.hip)
+    int sb_n3 = 0, sb_g1 = 0;  // its leading 3x3 K-groups / trailing 1x1 K-groups (sb_n3 < 0: segment order not supported by that flavour)
 };
 
 struct Tensor {
@@ -201,7 +204,8 @@ struct Op {
     int bn = 64;
     int glds_variant = 0;      // 0: 8 waves x 256 pixels, 1: 4 waves x 128 pixels
     int flavor = 0;            // 0: per-tap register-staged kernel (conv_igemm.hip); 2: LDS-DMA throughput kernel (conv_glds.hip);
-                               // 3: persistent ping-pong kernel (conv_pp.hip)
+                               // 3: persistent ping-pong kernel (conv_pp.hip); 4: small-batch kernel, K split over the waves of a workgroup (conv_sb.hip)
+    int sb_mt = 2, sb_nt = 2;  // flavour 4: 32-pixel / 32-cout MFMA blocks per workgroup
     int cvec_off = -1;         // EPI_EMB_SILU: offset of this block's c vector
     int out_C = 0, out_H = 0, out_W = 0;  // output tensor geometry (debug read-back)
     // ATTN
@@ -398,6 +402,22 @@ static int pack_conv(td_unet* u, ConvWeights& cw) {
     // tail padding: the LDS-DMA kernel over-reads 32 rows per tile and always fetches two K-steps past the end
     HIP_TRY(cw.packed->alloc(total * u->esize() + 2 * (size_t)cw.cout_pad * 128 + 16384, true));
     HIP_TRY(hipMemcpy(cw.packed->p, u->bf16 ? (const void*)stage16.data() : (const void*)stage.data(), total * u->esize(), hipMemcpyHostToDevice));
+    // small-batch flavour: a second copy in MFMA-fragment order (0.5 GB more for the 30m base model; 288 GB of HBM).  Every 3x3 segment must
+    // precede every 1x1 segment (true for every fused op of the U-Net); otherwise that flavour is simply not offered for this op
+    cw.sb_n3 = 0; cw.sb_g1 = 0;
+    if (u->bf16) {
+        bool seen1 = false;
+        for (auto& s : cw.segs) {
+            if (s.taps == 9) { if (seen1) { cw.sb_n3 = -1; break; } cw.sb_n3 += s.c_pad / chunk; }
+            else { seen1 = true; cw.sb_g1 += s.c_pad / chunk; }
+        }
+        if (cw.sb_n3 >= 0) {
+            cw.packed_sb.reset(new DevBuf());
+            HIP_TRY(cw.packed_sb->alloc(total * u->esize() + 16384, true));
+            HIP_TRY(launch_sb_repack(cw.packed->p, cw.packed_sb->p, cw.cout_pad, cw.sb_n3, cw.sb_g1, nullptr));
+            HIP_TRY(hipDeviceSynchronize());
+        }
+    }
     return TD_OK;
 }
 
@@ -540,7 +560,8 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
     // every option the plan builder reads is part of the cache key (a plan built under other options must never be reused)
     static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn", "pp",
                                                "pp_min_items_per_cu", "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
-                                               "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups", "glds_round_aware", "walk_alternate", "glds_tiny", "glds_dma1x1", "splitk_weighted"};
+                                               "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups", "glds_round_aware", "walk_alternate", "glds_tiny", "glds_dma1x1", "splitk_weighted",
+                                               "sb", "sb_target_wgs", "sb_mt", "sb_nt", "sb_order", "sb_max_glds_wgs"};
     std::string key = std::to_string(N) + "_" + std::to_string(H) + "_" + std::to_string(W);
     for (const char* o : kPlanOptions) key += "_" + std::to_string((long long)u->eng->option(o, -7));
     if (lane) key += "_lane" + std::to_string(lane);   // a second, independent activation set of the same shape (concurrent half-batches)
@@ -688,6 +709,29 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                     (pp_mode == 2 || pp_items >= u->eng->option("pp_min_items_per_cu", 2) * (int64_t)u->eng->n_cus)) {
                     op.flavor = 3; op.glds_variant = 0;
                     p.tiles_x = (w + 15) / 16; p.tiles_y = (h + 15) / 16; p.img_groups = N;
+                }
+                // Small-batch flavour (conv_sb.hip, round 4) wherever this launch would have split K over WORKGROUPS: K is split over the four waves
+                // of a workgroup instead and reduced through LDS -- no fp32 partial planes in HBM, no reduce launch (BASELINE configs[1]: one tile
+                // x 20 steps; the 1-16-window batches of the cascade's latent stage).  Tile: 64 px x 64 couts when that gives "sb_target_wgs"
+                // workgroups, else 64 x 32, else 32 x 32 (tools/sb_layers.sh has the per-level measurements).  Not in batch_invariant mode (p.ksplit
+                // stays 1 there and conv_glds is pinned): the K order differs from conv_glds, so the choice must not depend on the batch.
+                if (op.flavor == 2 && p.ksplit > 1 && u->eng->option("sb", 1) != 0 && cw.sb_n3 >= 0 && cw.packed_sb && wgs <= u->eng->option("sb_max_glds_wgs", 1 << 30)) {
+                    bool ok1 = true;
+                    for (int i = 0; i < p.nseg; ++i) if (p.seg[i].taps != 9 && p.seg[i].xform != 0) ok1 = false;
+                    if (ok1) {
+                        const int TWs = op.narrow ? 8 : 16;
+                        auto th_of = [&](int mt) { return op.narrow ? (mt == 2 ? 8 : 4) : (mt == 2 ? 4 : 2); };
+                        auto sb_wgs = [&](int mt, int nt) { return (int64_t)((w + TWs - 1) / TWs) * ((h + th_of(mt) - 1) / th_of(mt)) * N * (cw.cout_pad / (32 * nt)); };
+                        const int64_t target = u->eng->option("sb_target_wgs", 160);
+                        int mt = 1, nt = 1;
+                        if (sb_wgs(2, 2) >= target) { mt = 2; nt = 2; } else if (sb_wgs(2, 1) >= target) { mt = 2; nt = 1; }
+                        const int64_t fmt = u->eng->option("sb_mt", 0), fnt = u->eng->option("sb_nt", 0);   // test hooks
+                        if (fmt == 1 || fmt == 2) mt = (int)fmt;
+                        if (fnt == 1 || fnt == 2) nt = (int)fnt;
+                        op.flavor = 4; op.sb_mt = mt; op.sb_nt = nt; p.ksplit = 1;
+                        p.tiles_x = (w + TWs - 1) / TWs; p.tiles_y = (h + th_of(mt) - 1) / th_of(mt); p.img_groups = N; p.n_ntiles = cw.cout_pad / (32 * nt);
+                        p.wpack_sb = cw.packed_sb->p; p.sb_n3 = cw.sb_n3; p.sb_order = (int)u->eng->option("sb_order", 0);
+                    }
                 }
             }
         }
@@ -957,7 +1001,8 @@ static int run_unet(td_unet* u, Plan& pl, int step, const SchedCoef* fuse = null
             p.epi = EPI_DPM_STEP; p.dpm_x = (float*)pl.x->p; p.dpm_m1 = (float*)pl.m1->p; p.dpm_m2 = u->eng->option("solver_order", 2) == 3 ? (float*)pl.m2->p : nullptr; p.dpm_xin = pl.xin; p.dpm_xin_cstride = u->chunk; p.dpm_k = *fuse;
         }
         mark();
-        hipError_t e = op.flavor == 3 ? launch_conv_pp(p, u->dt, op.bn, u->eng->n_cus, st)
+        hipError_t e = op.flavor == 4 ? launch_conv_sb(p, u->dt, op.narrow, op.sb_mt, op.sb_nt, st)
+                       : op.flavor == 3 ? launch_conv_pp(p, u->dt, op.bn, u->eng->n_cus, st)
                        : op.flavor == 2 ? launch_conv_glds(p, u->dt, op.narrow, op.bn, op.glds_variant, st) : launch_conv(p, u->dt, op.narrow, op.bn, 0, st);
         mark(); if (prof) { ev_kind.push_back(0); char tag[128]; double gf_ = 0.0; for (int si_ = 0; si_ < p.nseg; ++si_) gf_ += (double)p.seg[si_].C * p.seg[si_].taps; gf_ *= 2.0 * p.N * p.H * p.W * p.Cout * 1e-9;  /* algorithmic GFLOP of this launch */
             /* algorithmic HBM megabytes of this launch: every source tensor once (at ITS resolution), the residual once, the outputs once, the weights once */
@@ -966,7 +1011,7 @@ static int run_unet(td_unet* u, Plan& pl, int step, const SchedCoef* fuse = null
             if (p.res) mb_ += (double)p.N * p.res_Hs * p.res_Ws * p.Cout * es_;
             mb_ += (double)p.N * p.H * p.W * p.Cout * (p.out_f32 ? 4.0 : es_) * (p.out2 ? 2.0 : 1.0);
             mb_ *= 1e-6;
-            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f mb%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 3 ? "p" : op.flavor == 2 ? (op.glds_variant == 2 ? "t" : op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_, mb_); ev_label.push_back(op.label + tag);
+            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f mb%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 4 ? (op.sb_mt == 2 ? (op.sb_nt == 2 ? "m2n2" : "m2n1") : (op.sb_nt == 2 ? "m1n2" : "m1n1")) : op.flavor == 3 ? "p" : op.flavor == 2 ? (op.glds_variant == 2 ? "t" : op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_, mb_); ev_label.push_back(op.label + tag);
             double kk = 0; for (int s_ = 0; s_ < p.nseg; ++s_) kk += (double)p.seg[s_].C * p.seg[s_].taps;
             ev_flop.push_back(op.flavor >= 2 ? 2.0 * p.N * p.H * p.W * (double)p.Cout * kk : 0.0); }
         if (e != hipSuccess) return fail(TD_ERR_HIP, "conv launch " + op.label + ": " + hipGetErrorString(e));

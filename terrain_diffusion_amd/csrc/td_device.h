@@ -86,6 +86,11 @@ struct ConvParams {
     int reverse;          // scheduling hint (speed only, never changes a bit): 1 = logical workgroup ids are walked backwards (the host alternates it
                           // from layer to layer: the producer's last-written, still cached rows are read first)
     int dma1x1;           // conv_glds: stream 1x1 segments by LDS-DMA when the launch qualifies (launch_glds_cfg decides)
+    // conv_sb.hip (small-batch flavour): the same weights in MFMA-fragment order [K-group][16-channel slice][tap][32-cout tile][lane][16 B]
+    const void* wpack_sb;
+    int sb_n3;            // number of leading 3x3 K-groups (every 3x3 segment precedes every 1x1 segment)
+    int sb_order;         // workgroup order (speed only): 0 = cout tiles of a pixel tile adjacent, 1 = pixel tiles of a cout tile adjacent
+    unsigned sb_d1, sb_m1, sb_m2, sb_m3, sb_grid8;   // launcher-made: first divisor of the workgroup-id decomposition, the magic multipliers (sb_udiv), grid / 8 (0 if 8 does not divide it)
 };
 
 // Split-K slice boundaries.  Uniform K-groups: the floor split s*kgroups/ksplit.  A mix of 3x3 and 1x1 groups (the decoder's conv_res1: 3x3 conv

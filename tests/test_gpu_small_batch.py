@@ -1,0 +1,134 @@
+"""GPU tests of the small-batch conv flavour (conv_sb.hip, engine option "sb", default on): K split over the four waves of a workgroup and
+reduced through LDS instead of fp32 partial planes in HBM + a reduce launch (BASELINE configs[1]: one 64x64 latent tile; the 1-16-window batches
+of the cascade's latent stage).  It replaces conv_glds wherever that would have split K over workgroups; its K order differs, so its results differ
+from conv_glds in bf16 rounding and are held to the same bounds against the reference: 2e-2 (bf16) / 4e-3 (fp16) rel-RMS per forward.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def td():
+    import terrain_diffusion_amd as t
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return t
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import rng, unet
+    return dict(rng=rng, unet=unet)
+
+
+@pytest.fixture(scope="module")
+def base(td, orc):
+    cfg = dict(orc["unet"].BASE_CONFIG)
+    sd = orc["unet"].synth_state_dict(cfg, seed=1234)
+    return {d: td.EDMUnet2D(**cfg, dtype=d).load_state_dict(sd) for d in ("bf16", "fp16")}
+
+
+def _inputs(orc, n):
+    x = torch.from_numpy(orc["rng"].standard_normal(7, (n, 5, 64, 64))).cuda()
+    c = torch.from_numpy(orc["rng"].standard_normal(8, (n, 58))).cuda()
+    return x, torch.full((n,), 1.1), [c]
+
+
+def _flavours(eng, model, args):
+    """flavour tag ('f4m2n2', 'f2s', ...) of every conv launch of one forward, from the engine's profile labels"""
+    import re
+    eng.set_option("profile", 1); eng.profile_read(reset=True)
+    try:
+        model(*args)
+        rows = eng.profile_ops()
+    finally:
+        eng.set_option("profile", 0); eng.profile_read(reset=True)
+    return {r[0].split(" [")[0]: re.search(r" (f\d\w*) bn", r[0]).group(1) for r in rows if " [" in r[0]}
+
+
+@pytest.mark.parametrize("dtype,tol", [("bf16", 2e-2), ("fp16", 4e-3)])
+def test_single_tile_forward_runs_on_the_small_batch_flavour_and_matches_the_reference(td, orc, golden, base, dtype, tol):
+    from terrain_diffusion_amd.engine import get_engine
+    eng = get_engine("cuda")
+    args = _inputs(orc, 1)
+    m = base[dtype]
+    y = m(*args)
+    err = rel_rms(y.cpu().numpy(), golden("unet")["base_out"])
+    fl = _flavours(eng, m, args)
+    n4 = sum(v.startswith("f4") for v in fl.values())
+    print(f"batch 1 {dtype}: {n4} of {len(fl)} conv launches on the small-batch flavour; rel-RMS vs reference {err:.3e}")
+    assert err < tol
+    assert n4 >= 70, fl   # every conv that used to split K over workgroups (78 of 79 at batch 1)
+    try:   # the same forward with the flavour switched off: conv_glds + split-K, same bound, and the two agree to bf16 rounding
+        eng.set_option("sb", 0)
+        y0 = m(*args)
+        assert not any(v.startswith("f4") for v in _flavours(eng, m, args).values())
+    finally:
+        eng.set_option("sb", 1)
+    assert rel_rms(y0.cpu().numpy(), golden("unet")["base_out"]) < tol
+    assert rel_rms(y.cpu().numpy(), y0.cpu().numpy()) < tol
+
+
+@pytest.mark.parametrize("mt,nt", [(2, 2), (2, 1), (1, 2), (1, 1)])
+def test_every_tile_shape_of_the_small_batch_flavour(td, orc, golden, base, mt, nt):
+    """test hooks sb_mt / sb_nt force one tile shape on every layer (64 / 32 pixels x 64 / 32 couts, 16-wide and 8-wide maps): each must hold
+    the reference bound on its own"""
+    from terrain_diffusion_amd.engine import get_engine
+    eng = get_engine("cuda")
+    args = _inputs(orc, 1)
+    try:
+        eng.set_option("sb_mt", mt); eng.set_option("sb_nt", nt)
+        y = base["bf16"](*args)
+        fl = _flavours(eng, base["bf16"], args)
+    finally:
+        eng.set_option("sb_mt", 0); eng.set_option("sb_nt", 0)
+    tag = f"f4m{mt}n{nt}"
+    assert sum(v == tag for v in fl.values()) >= 70, fl
+    err = rel_rms(y.cpu().numpy(), golden("unet")["base_out"])
+    print(f"sb tile m{mt} n{nt}: rel-RMS vs reference {err:.3e}")
+    assert err < 2e-2
+
+
+def test_small_batches_match_the_single_tile_results(td, orc, base):
+    """a window's result must not depend on what shares its batch beyond bf16 rounding (batches 2 ... 6 mix small-batch and throughput launches)"""
+    m = base["bf16"]
+    x, t, c = _inputs(orc, 6)
+    y6 = m(x, t, c)
+    for i in (0, 3, 5):
+        yi = m(x[i:i + 1].contiguous(), t[i:i + 1], [c[0][i:i + 1].contiguous()])
+        e = rel_rms(y6[i:i + 1].cpu().numpy(), yi.cpu().numpy())
+        assert e < 1e-2, (i, e)
+
+
+def test_ragged_map_and_workgroup_order(td, orc):
+    """maps that are not a multiple of the tile (72x72 -> 36, 18, 9 wide levels), both workgroup orders (sb_order), against the per-tap flavour
+    run of the same bf16 model (glds = 0, splitk = 0: no LDS-DMA kernel, no split-K)"""
+    from terrain_diffusion_amd.engine import get_engine
+    eng = get_engine("cuda")
+    cfg = orc["unet"].tiny_config(64, 1)
+    m = td.EDMUnet2D(**cfg, dtype="bf16").load_state_dict(orc["unet"].synth_state_dict(cfg, seed=77))
+    n_cond = 58   # BASE_CONFIG's one tensor input
+    x = torch.from_numpy(orc["rng"].standard_normal(17, (2, cfg["in_channels"], 72, 72))).cuda()
+    c = torch.from_numpy(orc["rng"].standard_normal(18, (2, n_cond))).cuda()
+    t = torch.full((2,), 0.9)
+    try:
+        eng.set_option("glds", 0); eng.set_option("splitk", 0)
+        ref = m(x, t, [c])
+    finally:
+        eng.set_option("glds", 1); eng.set_option("splitk", 1)
+    for order in (0, 1):
+        try:
+            eng.set_option("sb_order", order)
+            y = m(x, t, [c])
+            fl = _flavours(eng, m, (x, t, [c]))
+        finally:
+            eng.set_option("sb_order", 0)
+        assert any(v.startswith("f4") for v in fl.values()), fl
+        e = rel_rms(y.cpu().numpy(), ref.cpu().numpy())
+        print(f"ragged 72x72, sb_order {order}: rel-RMS vs the per-tap flavour {e:.3e}")
+        assert e < 1e-2, (order, e)
+    m.close()
