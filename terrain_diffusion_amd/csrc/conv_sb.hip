@@ -88,12 +88,14 @@ __global__ __launch_bounds__(256, 2) void conv_sb_kernel(const ConvParams p) {
 #endif
 
     // ---- kernel arguments of the prologue, one burst (the empty asm pins them: loaded together, waited for once)
-    unsigned k_d1 = p.sb_d1, k_m1 = p.sb_m1, k_m2 = p.sb_m2, k_m3 = p.sb_m3, k_g8 = p.sb_grid8;
+    unsigned k_d1 = p.sb_d1, k_m1 = p.sb_m1, k_m2 = p.sb_m2, k_m3 = p.sb_m3, k_g8 = p.sb_grid8, k_d0 = p.sb_d0, k_m0 = p.sb_m0;
+    int k_ks = p.ksplit;
     int k_order = p.sb_order, k_tx = p.tiles_x, k_ty = p.tiles_y, k_N = p.N, k_H = p.H, k_W = p.W, k_cpad = p.CoutPad, k_n3 = p.sb_n3, k_ng = p.kgroups;
     const unsigned char* k_wsb = (const unsigned char*)p.wpack_sb;
     const T* k_s0src = (const T*)p.seg[0].src;
     int k_s0C = p.seg[0].C, k_s0cs = p.seg[0].cstride, k_s0Hs = p.seg[0].Hs, k_s0Ws = p.seg[0].Ws, k_s0rs = p.seg[0].resample, k_s0xf = p.seg[0].xform;
     float k_s0sc = p.seg[0].scale;
+    asm volatile("" : "+s"(k_d0), "+s"(k_m0), "+s"(k_ks));
     asm volatile("" : "+s"(k_d1), "+s"(k_m1), "+s"(k_m2), "+s"(k_m3), "+s"(k_g8), "+s"(k_order), "+s"(k_tx), "+s"(k_ty), "+s"(k_N), "+s"(k_H), "+s"(k_W),
                  "+s"(k_cpad), "+s"(k_n3), "+s"(k_ng), "+s"(k_wsb), "+s"(k_s0src), "+s"(k_s0C), "+s"(k_s0cs), "+s"(k_s0Hs), "+s"(k_s0Ws), "+s"(k_s0rs), "+s"(k_s0xf), "+s"(k_s0sc));
 
@@ -101,12 +103,20 @@ __global__ __launch_bounds__(256, 2) void conv_sb_kernel(const ConvParams p) {
     if (k_g8) bid = (bid & 7) * k_g8 + (bid >> 3);   // XCD x takes a contiguous range of logical ids (speed only; k_g8 = grid / 8 when 8 divides it)
     // logical id -> (cout tile, pixel tile).  sb_order 0: the cout tiles of a pixel tile are adjacent (they share the halo patch in an XCD's L2),
     // 1: the pixel tiles of a cout tile are adjacent (an XCD's L2 then holds few cout tiles' weights).  Divisions by host-made magic numbers.
+    // split-K over workgroups (k_ks > 1, the weight-streaming-bound deep levels at batch 1: see the planner): slice ksp is the outermost index
+    const unsigned ksp = k_ks > 1 ? sb_udiv(bid, k_d0, k_m0) : 0u;
+    bid -= ksp * k_d0;
     const unsigned q1 = sb_udiv(bid, k_d1, k_m1), r1 = bid - q1 * k_d1;
     const unsigned ntile = k_order ? q1 : r1, mtile = k_order ? r1 : q1;
     const unsigned q2 = sb_udiv(mtile, (unsigned)k_tx, k_m2), txi = mtile - q2 * (unsigned)k_tx;
     const int n0 = (int)sb_udiv(q2, (unsigned)k_ty, k_m3), tyi = (int)(q2 - (unsigned)n0 * (unsigned)k_ty);
     const int y0 = tyi * TH, x0 = (int)txi * TW, co0 = (int)ntile * (NT * 32);
-    const int NCT = k_cpad / 32, n3 = k_n3, ngroups = k_ng;
+    const int NCT = k_cpad / 32, n3 = k_n3;
+    // K-groups of this workgroup: [g_lo, g_hi) (everything without split-K; conv_set_kbounds slices balanced by K-steps otherwise): the 3x3 groups
+    // [a3, b3) and the 1x1 groups [a1, ngroups) behind them
+    int g_lo = 0, g_hi = k_ng;
+    if (k_ks > 1) { g_lo = p.kb[ksp]; g_hi = p.kb[ksp + 1]; }
+    const int a3 = g_lo < n3 ? g_lo : n3, b3 = g_hi < n3 ? g_hi : n3, a1 = g_lo > n3 ? g_lo : n3, ngroups = g_hi;
 
     // ---- weight stream: this lane's 16 bytes of (K-group g, slice `wave`, tap t, cout tile ct0 + j) live at wl3 + ((g * 36 + t) * NCT + j) * 1024
     // for the 3x3 groups and at wl1 + (((g - n3) * 4) * NCT + j) * 1024 for the 1x1 groups behind them.  Group 0's nine taps are requested first.
@@ -114,11 +124,12 @@ __global__ __launch_bounds__(256, 2) void conv_sb_kernel(const ConvParams p) {
     const unsigned char* wl3 = k_wsb + ((size_t)(wave * 9) * NCT + co0 / 32) * 1024 + lane * 16;
     const unsigned char* wl1 = k_wsb + ((size_t)n3 * 36 * NCT + (size_t)wave * NCT + co0 / 32) * 1024 + lane * 16;
     u32x4 wr[9][NT];
-    if (n3 > 0) {
+    if (a3 < b3) {
+        const unsigned char* w0 = wl3 + (size_t)a3 * 36 * tstep;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) wr[t][j] = sb_gld<u32x4>(wl3 + t * tstep + j * 1024);
+            for (int j = 0; j < NT; ++j) wr[t][j] = sb_gld<u32x4>(w0 + t * tstep + j * 1024);
     }
 #ifdef TD_TRACE
     TD_ST(tra);
@@ -179,7 +190,12 @@ __global__ __launch_bounds__(256, 2) void conv_sb_kernel(const ConvParams p) {
             }                                                                                          \
         }                                                                                              \
     }
-    if (n3 > 0) TD_LOAD_A();
+    if (a3 < b3) {
+        int gl = a3;   // a later split-K slice starts inside the K range: walk the cursor to its first group
+        while (gl >= cnch) { gl -= cnch; TD_SEG_NEXT(); }
+        cchunk = gl;
+        TD_LOAD_A();
+    }
 #ifdef TD_TRACE
     TD_ST(trb);
 #endif
@@ -273,8 +289,8 @@ __global__ __launch_bounds__(256, 2) void conv_sb_kernel(const ConvParams p) {
     // the first group is peeled: the prologue requests weights BEFORE the patch (they depend on nothing but the workgroup id), the loop the other
     // way round, and hipcc merges the loop-entry and back-edge wait-count states -- entering the loop from the prologue would cost a drain of
     // the refill queue (vmcnt(3)) in front of every restage
-    if (n3 > 1) TD_GROUP(0, true);
-    for (int g = 1; g + 1 < n3; ++g) TD_GROUP(g, true);
+    if (b3 - a3 > 1) TD_GROUP(a3, true);
+    for (int g = a3 + 1; g + 1 < b3; ++g) TD_GROUP(g, true);
 
     TD_ST(tr3);
     // ---------------- before the last 3x3 group: everything the tail needs from memory.  Epilogue kernel arguments in one burst ...
@@ -309,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void conv_sb_kernel(const ConvParams p) {
         for (int m = 0; m < 2; ++m) { ca[m] = sb_gld<f32x4>(crow + m * 16); cb[m] = sb_gld<f32x4>(crow + m * 16 + 8); rw[m] = sb_gld<u32x4>(rrow + m * 16); }
     }
 
-    if (n3 > 0) TD_GROUP(n3 - 1, false);
+    if (a3 < b3) TD_GROUP(b3 - 1, false);
 #undef TD_GROUP
 #undef TD_TOFF
 #undef TD_SEG_NEXT
@@ -318,14 +334,14 @@ __global__ __launch_bounds__(256, 2) void conv_sb_kernel(const ConvParams p) {
 
     // ---------------- 1x1 K-groups: both operands straight from global memory, no LDS and no barrier; batches of D1 groups (a batch's loads
     // are requested while the previous batch is contracted; whole 1x1 phases of <= D1 groups -- most of them -- are one request burst)
-    if (n3 < ngroups) {
+    if (a1 < ngroups) {
         constexpr int D1 = 8;
         int sg1 = 0;
         while (sg1 < p.nseg && p.seg[sg1].taps == 9) ++sg1;   // first 1x1 segment
         u32x4 wa[D1][NT], xa[D1][MT];
         int poff[MT];           // element offset of this lane's pixel (+ its 8 channels of the wave's slice) in the segment's source
         const T* psrc = nullptr; int pn = 0, pseg = sg1 - 1, pchunk = 0;   // prefetch cursor
-        const unsigned char* pw = wl1;
+        const unsigned char* pw = wl1 + (size_t)(a1 - n3) * 4 * tstep;
         auto seg_open = [&]() {
             ++pseg; pchunk = 0;
             const ConvSeg& sg_ = p.seg[pseg];
@@ -341,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv_sb_kernel(const ConvParams p) {
                 poff[i] = pix * cs_ + wave * 16 + lh * 8;
             }
         };
-        int pleft = ngroups - n3;   // groups the prefetch cursor has not issued yet
+        int pleft = ngroups - a1;   // groups the prefetch cursor has not issued yet
         auto issue = [&](int slot_) {   // slot_ is a compile-time constant at every call site
             if (pleft > 0) {
                 if (pchunk == pn) seg_open();
@@ -353,9 +369,10 @@ __global__ __launch_bounds__(256, 2) void conv_sb_kernel(const ConvParams p) {
             }
         };
         seg_open();
+        { int gl = a1 - n3; while (gl >= pn) { gl -= pn; seg_open(); } pchunk = gl; }   // a later split-K slice starts inside the 1x1 range
 #pragma unroll
         for (int d = 0; d < D1; ++d) issue(d);
-        for (int g = n3; g < ngroups; g += D1) {
+        for (int g = a1; g < ngroups; g += D1) {
 #pragma unroll
             for (int d = 0; d < D1; ++d) {
                 if (g + d < ngroups) {
@@ -397,6 +414,14 @@ __global__ __launch_bounds__(256, 2) void conv_sb_kernel(const ConvParams p) {
 #pragma unroll
             for (int w = 1; w < NW; ++w) s += *(const f32x4*)(smem + ((w * MT * NT + q) * 4 + rg) * 1024 + lane * 16);
             a4[rg] = s;
+        }
+        if (k_ks > 1) {   // raw fp32 partial sums [ksplit][pixel][CoutPad]; conv_splitk_reduce_kernel adds the slices in fixed order + epilogue
+            if (eok) {
+                float* prow = p.partial + ((size_t)ksp * M + ((size_t)en * k_H + ey) * k_W + ex) * k_cpad + cot + 4 * lh;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) *(f32x4*)(prow + rg * 8) = a4[rg];
+            }
+            return;
         }
         float ssj = 0.f;
         if (eok) {
@@ -453,7 +478,7 @@ static hipError_t launch_sb_cfg(const ConvParams& p, hipStream_t st) {
     constexpr int MT = TH * TW / 32, NPATCH = (TH + 2) * (TW == 8 ? 12 : TW + 2);
     constexpr int A2 = 2 * NPATCH * 144, RED = 4 * MT * NT * 4096;
     constexpr size_t lds = (size_t)(A2 > RED ? A2 : RED) + NPATCH * 4;
-    if (!p.wpack_sb || p.ksplit != 1 || p.CoutPad % (NT * 32) != 0) return hipErrorInvalidValue;
+    if (!p.wpack_sb || p.ksplit < 1 || p.ksplit > 64 || (p.ksplit > 1 && !p.partial) || p.CoutPad % (NT * 32) != 0) return hipErrorInvalidValue;
     bool seen1 = false;   // every 3x3 segment before every 1x1 segment (the weight stream's addressing relies on it), 1x1 sources untransformed
     int n3 = 0;
     for (int s = 0; s < p.nseg; ++s) {
@@ -461,9 +486,10 @@ static hipError_t launch_sb_cfg(const ConvParams& p, hipStream_t st) {
         else { seen1 = true; if (p.seg[s].xform != 0) return hipErrorInvalidValue; }
     }
     if (n3 != p.sb_n3) return hipErrorInvalidValue;
-    const int mtiles = p.tiles_x * p.tiles_y * p.img_groups, grid = p.n_ntiles * mtiles;
-    if (grid <= 0 || (long long)grid * std::max(mtiles, p.n_ntiles) >= ((long long)1 << 32)) return hipErrorInvalidValue;   // sb_udiv's range
+    const int mtiles = p.tiles_x * p.tiles_y * p.img_groups, grid1 = p.n_ntiles * mtiles, grid = grid1 * p.ksplit;
+    if (grid1 <= 0 || (long long)grid * std::max(grid1, std::max(mtiles, p.n_ntiles)) >= ((long long)1 << 32)) return hipErrorInvalidValue;   // sb_udiv's range
     ConvParams q = p;
+    q.sb_d0 = grid1; q.sb_m0 = sb_magic(grid1);
     q.sb_d1 = p.sb_order ? mtiles : p.n_ntiles; q.sb_m1 = sb_magic(q.sb_d1); q.sb_m2 = sb_magic(p.tiles_x); q.sb_m3 = sb_magic(p.tiles_y);
     q.sb_grid8 = (grid & 7) == 0 ? (unsigned)grid >> 3 : 0u;
     auto kern = conv_sb_kernel<T, TH, TW, NT>;
@@ -477,11 +503,17 @@ static hipError_t launch_sb_cfg(const ConvParams& p, hipStream_t st) {
         }
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, q);
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && p.ksplit > 1) {
+        const size_t W_ = (size_t)p.N * p.H * p.W * ((p.CoutPad + 255) / 256);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel<T>, dim3((unsigned)((W_ + 3) / 4)), dim3(256), 0, st, p);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 // Tile configurations: mt = 32-pixel MFMA blocks per workgroup (2: 4x16 or 8x8 pixels, 1: 2x16 or 4x8), nt = 32-cout blocks (1 or 2).
-// The caller sets tiles_x / tiles_y for that tile, img_groups = N, n_ntiles = CoutPad / (32 nt), ksplit = 1.
+// The caller sets tiles_x / tiles_y for that tile, img_groups = N, n_ntiles = CoutPad / (32 nt), ksplit (+ kb[], partial when > 1).
 template <typename T>
 static hipError_t launch_conv_sb_t(const ConvParams& p, bool narrow, int mt, int nt, hipStream_t st) {
     if (!narrow) {

@@ -561,7 +561,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
     static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn", "pp",
                                                "pp_min_items_per_cu", "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
                                                "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups", "glds_round_aware", "walk_alternate", "glds_tiny", "glds_dma1x1", "splitk_weighted",
-                                               "sb", "sb_target_wgs", "sb_mt", "sb_nt", "sb_order", "sb_max_glds_wgs"};
+                                               "sb", "sb_target_wgs", "sb_mt", "sb_nt", "sb_order", "sb_max_glds_wgs", "sb_splitk", "sb_splitk_wgs", "sb_splitk_max"};
     std::string key = std::to_string(N) + "_" + std::to_string(H) + "_" + std::to_string(W);
     for (const char* o : kPlanOptions) key += "_" + std::to_string((long long)u->eng->option(o, -7));
     if (lane) key += "_lane" + std::to_string(lane);   // a second, independent activation set of the same shape (concurrent half-batches)
@@ -673,7 +673,9 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                 const double t128 = (double)((w128 + slots_ - 1) / slots_) * 128.0, t96 = (double)((w96 + slots_ - 1) / slots_) * 96.0 * 1.03;
                 if (t96 < 0.9 * t128) bn2 = 96;
             }
-            if (u->bf16 && bn2 && u->eng->option("glds", 1) && (inv || mt2 * (cw.cout_pad / bn2) >= u->eng->option("glds_min_wgs", 8))) {
+            // (grids below "glds_min_wgs" used to fall to the per-tap flavour; with the small-batch flavour available they enter here and take it)
+            const bool sb_avail = u->bf16 && !inv && u->eng->option("sb", 1) != 0 && cw.sb_n3 >= 0 && cw.packed_sb;
+            if (u->bf16 && bn2 && u->eng->option("glds", 1) && (inv || sb_avail || mt2 * (cw.cout_pad / bn2) >= u->eng->option("glds_min_wgs", 8))) {
                 op.flavor = 2; op.bn = bn2; op.glds_variant = variant;
                 int TH2 = variant ? 8 : (op.narrow ? 8 : 16);
                 const int NIMG2 = op.narrow ? (variant ? 2 : 4) : 1;
@@ -710,12 +712,15 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                     op.flavor = 3; op.glds_variant = 0;
                     p.tiles_x = (w + 15) / 16; p.tiles_y = (h + 15) / 16; p.img_groups = N;
                 }
-                // Small-batch flavour (conv_sb.hip, round 4) wherever this launch would have split K over WORKGROUPS: K is split over the four waves
-                // of a workgroup instead and reduced through LDS -- no fp32 partial planes in HBM, no reduce launch (BASELINE configs[1]: one tile
-                // x 20 steps; the 1-16-window batches of the cascade's latent stage).  Tile: 64 px x 64 couts when that gives "sb_target_wgs"
-                // workgroups, else 64 x 32, else 32 x 32 (tools/sb_layers.sh has the per-level measurements).  Not in batch_invariant mode (p.ksplit
-                // stays 1 there and conv_glds is pinned): the K order differs from conv_glds, so the choice must not depend on the batch.
-                if (op.flavor == 2 && p.ksplit > 1 && u->eng->option("sb", 1) != 0 && cw.sb_n3 >= 0 && cw.packed_sb && wgs <= u->eng->option("sb_max_glds_wgs", 1 << 30)) {
+                // Small-batch flavour (conv_sb.hip, round 4) wherever the throughput tiles do not fill the chip (workgroups x 2 <= CU slots: the
+                // launches that used to split K over WORKGROUPS).  K is split over the four waves of a workgroup and reduced through LDS: no fp32
+                // partial planes in HBM, no reduce launch (BASELINE configs[1]: one tile x 20 steps; the 1-16-window batches of the cascade's latent
+                // stage).  Tile: 64 px x 64 couts when that gives "sb_target_wgs" workgroups, else 64 x 32, else 32 x 32.  The weight-streaming-bound
+                // deep levels (one tile: 8x8 and 16x16 maps, 6 - 21 MB of weights per conv against 24 - 144 workgroups that each ingest <= ~85 GB/s)
+                // additionally split K over workgroups, 64 x 32 tiles, ~224 workgroups in all: the partial planes there are small (64 - 256 pixels)
+                // and the reduce launch costs less than the weight stream gains (tools/sb_splitk.sh: 8x8 1536->768 39 -> 17 us cold).
+                // Not in batch_invariant mode (conv_glds stays pinned): the K order differs, so the choice must not depend on the batch.
+                if (op.flavor == 2 && sb_avail && wgs * 2 <= slots && wgs <= u->eng->option("sb_max_glds_wgs", 1 << 30)) {
                     bool ok1 = true;
                     for (int i = 0; i < p.nseg; ++i) if (p.seg[i].taps != 9 && p.seg[i].xform != 0) ok1 = false;
                     if (ok1) {
@@ -723,12 +728,16 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                         auto th_of = [&](int mt) { return op.narrow ? (mt == 2 ? 8 : 4) : (mt == 2 ? 4 : 2); };
                         auto sb_wgs = [&](int mt, int nt) { return (int64_t)((w + TWs - 1) / TWs) * ((h + th_of(mt) - 1) / th_of(mt)) * N * (cw.cout_pad / (32 * nt)); };
                         const int64_t target = u->eng->option("sb_target_wgs", 160);
-                        int mt = 1, nt = 1;
+                        int mt = 1, nt = 1, ks = 1;
                         if (sb_wgs(2, 2) >= target) { mt = 2; nt = 2; } else if (sb_wgs(2, 1) >= target) { mt = 2; nt = 1; }
+                        else if (use_splitk && u->eng->option("sb_splitk", 1) != 0 && sb_wgs(2, 1) * 2 <= u->eng->option("sb_splitk_wgs", 224)) {
+                            mt = 2; nt = 1;
+                            ks = (int)std::min<int64_t>(std::min<int64_t>(kgroups, u->eng->option("sb_splitk_max", 16)), (u->eng->option("sb_splitk_wgs", 224) + sb_wgs(2, 1) / 2) / sb_wgs(2, 1));
+                        }
                         const int64_t fmt = u->eng->option("sb_mt", 0), fnt = u->eng->option("sb_nt", 0);   // test hooks
-                        if (fmt == 1 || fmt == 2) mt = (int)fmt;
-                        if (fnt == 1 || fnt == 2) nt = (int)fnt;
-                        op.flavor = 4; op.sb_mt = mt; op.sb_nt = nt; p.ksplit = 1;
+                        if (fmt == 1 || fmt == 2) { mt = (int)fmt; ks = 1; }
+                        if (fnt == 1 || fnt == 2) { nt = (int)fnt; ks = 1; }
+                        op.flavor = 4; op.sb_mt = mt; op.sb_nt = nt; p.ksplit = ks < 1 ? 1 : ks;
                         p.tiles_x = (w + TWs - 1) / TWs; p.tiles_y = (h + th_of(mt) - 1) / th_of(mt); p.img_groups = N; p.n_ntiles = cw.cout_pad / (32 * nt);
                         p.wpack_sb = cw.packed_sb->p; p.sb_n3 = cw.sb_n3; p.sb_order = (int)u->eng->option("sb_order", 0);
                     }

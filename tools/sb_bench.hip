@@ -84,6 +84,11 @@ int main(int argc, char** argv) {
     // ---- sb
     ConvParams ps = p; ps.out = out; ps.out_sumsq = ssq; ps.out2 = o2; ps.wpack_sb = wsb; ps.sb_n3 = n3; ps.sb_order = order;
     { const int TW = narrow ? 8 : 16, TH = narrow ? (mt == 2 ? 8 : 4) : (mt == 2 ? 4 : 2); ps.tiles_x = (W + TW - 1) / TW; ps.tiles_y = (H + TH - 1) / TH; ps.img_groups = N; ps.n_ntiles = CoutPad / (32 * nt); }
+    const int sb_ks = A(15, 1);   // split-K over workgroups on top of the in-workgroup split (+ reduce launch)
+    if (sb_ks > 1) {
+        float* part; CK(hipMalloc(&part, (size_t)sb_ks * M * CoutPad * 4)); ps.partial = part; ps.ksplit = sb_ks;
+        if (!conv_set_kbounds(ps, true)) { printf("bad sb split-K\n"); return 1; }
+    }
     CK(hipMemset(out, 0, M * CoutPad * 4));
     CK(launch_conv_sb(ps, 1, narrow, mt, nt, st));
     CK(hipStreamSynchronize(st));
@@ -120,8 +125,8 @@ int main(int argc, char** argv) {
     const double flop = 2.0 * M * Cout * ((double)Cin * 9 + Cin1), wmb = (double)ksteps * CoutPad * 128 * 1e-6;
     const float t_sb = timeit([&] { return launch_conv_sb(ps, 1, narrow, mt, nt, st); });
     const float c_sb = cold([&] { return launch_conv_sb(ps, 1, narrow, mt, nt, st); });
-    printf("N%d %dx%d C%d+%d(1x1) -> %d mt%d nt%d epi%d xf%d ord%d rs%d | sb: hot %.1f us (%.0f TF/s)  cold %.1f us (%.0f GB/s of %.2f MB weights)  wgs=%d\n", N, H, W, Cin, Cin1, Cout, mt, nt, epi, xform, order, resample,
-           t_sb, flop / t_sb * 1e-6, c_sb, wmb / c_sb * 1e3, wmb, ps.n_ntiles * ps.tiles_x * ps.tiles_y * ps.img_groups);
+    printf("N%d %dx%d C%d+%d(1x1) -> %d mt%d nt%d epi%d xf%d ord%d rs%d ks%d | sb: hot %.1f us (%.0f TF/s)  cold %.1f us (%.0f GB/s of %.2f MB weights)  wgs=%d\n", N, H, W, Cin, Cin1, Cout, mt, nt, epi, xform, order, resample, sb_ks,
+           t_sb, flop / t_sb * 1e-6, c_sb, wmb / c_sb * 1e3, wmb, ps.n_ntiles * ps.tiles_x * ps.tiles_y * ps.img_groups * sb_ks);
 #ifdef SB_WITH_GLDS
     if (glds_ks > 0) {
         ConvParams pg = p; pg.out = out_ref; pg.out_sumsq = ssq_ref; pg.out2 = o2_ref; pg.ksplit = glds_ks;
