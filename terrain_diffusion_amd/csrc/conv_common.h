@@ -201,9 +201,28 @@ __device__ __forceinline__ float epilogue4(const ConvParams& p, int n, int y, in
     return ss;
 }
 
+// The partial sums of squares are independent loads: requested eight at a time (a rolled loop waits for each one -- up to 24 memory round
+// trips in series in front of a kernel's first restage), added in ascending order as before.
 __device__ __forceinline__ float pixel_rn(const float* sumsq, int nparts, size_t npix, int sp, float inv_c) {
     float s = 0.f;
-    for (int q = 0; q < nparts; ++q) s += sumsq[(size_t)q * npix + sp];
+    const float* b = sumsq + sp;
+    int q = 0;
+    for (; q + 8 <= nparts; q += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = b[(size_t)(q + u) * npix];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    if (q + 4 <= nparts) {
+        float t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = b[(size_t)(q + u) * npix];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += t[u];
+        q += 4;
+    }
+    for (; q < nparts; ++q) s += b[(size_t)q * npix];
     return 1.f / (1e-4f + sqrtf(s * inv_c));  // mp_layers.py:9-12 with dim=1: x / (eps + ||x||_c / sqrt(C))
 }
 
@@ -214,6 +233,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TD_GLDS16(VOFF, SBASE, LDS_BASE, IMM)                                                                 \
     asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                          \
                  ::"v"(VOFF), "s"(SBASE), "s"(LDS_BASE), "n"(IMM) : "memory", "scc")
+
+// exact a / d for a < 2^32 / d with M = ceil(2^32 / d) (host: td_magic); d == 1 has no 32-bit M.  The workgroup-id decomposition of the conv
+// kernels: a run-time integer division is ~40 scalar + vector instructions (v_rcp_iflag_f32 + corrections), and a kernel prologue had six of them
+__device__ __forceinline__ unsigned td_udiv(unsigned a, unsigned d, unsigned M) { return d == 1 ? a : __umulhi(a, M); }
+static inline unsigned td_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((((unsigned long long)1 << 32) + d - 1) / d); }
+// 16-byte load with an explicit GLOBAL address space (a pointer that went through an asm register pin loses hipcc's address-space inference and
+// would be accessed with FLAT instructions, which count on lgkmcnt as well as vmcnt and collide with every LDS wait)
+__device__ __forceinline__ u32x4 td_gld16(const void* q) { return *(const __attribute__((address_space(1))) u32x4*)q; }
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // v_permlane32_swap: lanes 32-63 of a exchange with lanes 0-31 of b (both halves of a wave take part)

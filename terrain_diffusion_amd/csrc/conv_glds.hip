@@ -71,22 +71,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
     // XCD-aware order (workgroup b runs on XCD b % 8; only speed depends on it): XCD x takes the contiguous range [x*G/8, (x+1)*G/8) of
     // logical ids, so the n_ntiles cout-tile siblings of a pixel tile (consecutive logical ids) run on ONE XCD at about the same time and
     // share its L2 copy of the halo patch instead of fetching it from HBM once per sibling.
-    int bid = blockIdx.x;
+    // Workgroup-id decomposition.  Round 4: the decode constants come in ONE burst of kernel-argument loads pinned by an empty asm statement, the
+    // divisions are multiplications by launcher-made magic numbers (td_udiv), and the grid size is a kernel argument instead of a read of the
+    // dispatch packet: hipcc used to emit a dozen serialised scalar loads (each one a scalar-cache round trip, the first a ~1 us miss) plus six
+    // ~40-instruction integer divisions here, i.e. several thousand cycles before the first weight request of every workgroup.
+    unsigned k_d0 = p.sb_d0, k_m0 = p.sb_m0, k_d1 = p.sb_d1, k_m1 = p.sb_m1, k_m2 = p.sb_m2, k_m3 = p.sb_m3, k_g8 = p.sb_grid8, k_grid = p.sb_grid;
+    int k_tx = p.tiles_x, k_ty = p.tiles_y, k_rev = p.reverse, k_ks = p.ksplit, k_kg = p.kgroups, k_cpad = p.CoutPad, k_N = p.N, k_H = p.H, k_W = p.W;
+    const unsigned char* k_wpack = (const unsigned char*)p.wpack;   // only ever the scalar base of an LDS-DMA statement: no address space to lose
+    asm volatile("" : "+s"(k_cpad), "+s"(k_N), "+s"(k_H), "+s"(k_W), "+s"(k_wpack));
+    asm volatile("" : "+s"(k_d0), "+s"(k_m0), "+s"(k_d1), "+s"(k_m1), "+s"(k_m2), "+s"(k_m3), "+s"(k_g8), "+s"(k_grid), "+s"(k_tx), "+s"(k_ty), "+s"(k_rev), "+s"(k_ks), "+s"(k_kg));
+    unsigned ubid = blockIdx.x;
 #ifndef TD_NO_XCD_REMAP
-    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    if (k_g8) ubid = (ubid & 7) * k_g8 + (ubid >> 3);
 #endif
     // the host alternates `reverse` from layer to layer: a layer then reads first what its producer wrote last, which is still in the 256 MB
     // Infinity Cache (chained A/B on the 192-channel 64x64 layers: -7...-11 % time; profiles/r03_conv_walk_order_and_stagger.txt)
-    if (p.reverse) bid = (int)gridDim.x - 1 - bid;
-    const int ntile = bid % p.n_ntiles; bid /= p.n_ntiles;
-    const int mtiles = p.tiles_x * p.tiles_y * p.img_groups;
-    const int mtile = bid % mtiles;
-    const int ksp = bid / mtiles;  // split-K index: this workgroup reduces K-groups [g0, g1) and leaves fp32 partials to the reduce kernel
-    const int txi = mtile % p.tiles_x, tyi = (mtile / p.tiles_x) % p.tiles_y, ig = mtile / (p.tiles_x * p.tiles_y);
+    if (k_rev) ubid = k_grid - 1 - ubid;
+    const unsigned q1 = td_udiv(ubid, k_d1, k_m1);
+    const int ntile = (int)(ubid - q1 * k_d1);
+    const int ksp = (int)td_udiv(q1, k_d0, k_m0);  // split-K index: this workgroup reduces K-groups [g0, g1) and leaves fp32 partials to the reduce kernel
+    const unsigned mtile = q1 - (unsigned)ksp * k_d0;
+    const unsigned q2 = td_udiv(mtile, (unsigned)k_tx, k_m2);
+    const int txi = (int)(mtile - q2 * (unsigned)k_tx), ig = (int)td_udiv(q2, (unsigned)k_ty, k_m3), tyi = (int)(q2 - (unsigned)ig * (unsigned)k_ty);
     const int n0 = ig * NIMG, y0 = tyi * TH, x0 = txi * TW, co0 = ntile * BN;
-    const int g0 = p.kb[ksp], g1 = p.kb[ksp + 1];  // conv_set_kbounds (host)
+    int g0 = 0, g1 = k_kg;   // conv_set_kbounds (host); the byte table is only read when K is split
+    if (k_ks > 1) { g0 = p.kb[ksp]; g1 = p.kb[ksp + 1]; }
     int seg_first = 0, chunk_first = 0, kstep_first = 0;  // (segment, chunk) of K-group g0 and the K-step it starts at
-    {
+    if (g0 > 0) {   // (without split-K there is nothing to look for: the walk costs two or three serialised kernel-argument loads per segment)
         int g = 0;
         while (seg_first < p.nseg) {
             const int nch = p.seg[seg_first].C / CHUNK;
@@ -97,8 +108,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
 
     // ---- weight ring.  wnext is the (wave-uniform, SGPR) address of the next tile to fetch; every tap fetches the tile two K-steps
     // ahead UNCONDITIONALLY (the packed slab carries two K-steps of tail padding), so the loop has no tail tests and a fixed vmcnt.
-    const size_t wstep = (size_t)p.CoutPad * 128;
-    const unsigned char* wnext = (const unsigned char*)p.wpack + (size_t)co0 * 128 + (size_t)kstep_first * wstep;
+    const size_t wstep = (size_t)k_cpad * 128;
+    const unsigned char* wnext = k_wpack + (size_t)co0 * 128 + (size_t)kstep_first * wstep;
     unsigned wvoff[NBI];
 #pragma unroll
     for (int i = 0; i < NBI; ++i) wvoff[i] = (unsigned)tid * 16u + (unsigned)i * NTHR * 16u;
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
         const int e = tid + it * NTHR, pp = e >> 3;
         const int img = pp / PPI, r = pp % PPI, py = r / PW, px = r % PW;
         const int n = n0 + img, y = y0 + py - 1, x = x0 + px - 1;
-        const bool ok = (pp < NPATCH) && px < TW + 2 && n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W;  // px >= TW+2: pad columns
+        const bool ok = (pp < NPATCH) && px < TW + 2 && n < k_N && y >= 0 && y < k_H && x >= 0 && x < k_W;  // px >= TW+2: pad columns
         const bool interior = py >= 1 && py <= TH && px >= 1 && px <= TW;
         a_coord[it] = ok ? ((n << 21) | (y << 11) | (x << 1) | (interior ? 1 : 0)) : -1;
     }
@@ -609,6 +620,12 @@ static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
     constexpr bool HAS_DMA = true;
     if (dma) lds = std::max(lds, LDS_STAGES + (size_t)g_bench_extra_lds);
     pd.dma1x1 = dma ? 1 : 0;
+    {   // workgroup-id decode constants of the kernel prologue
+        const int mtiles_ = p.tiles_x * p.tiles_y * p.img_groups;
+        if (grid <= 0 || (long long)grid * std::max(mtiles_, p.n_ntiles) >= ((long long)1 << 32)) return hipErrorInvalidValue;   // td_udiv's range
+        pd.sb_d0 = mtiles_; pd.sb_m0 = td_magic(mtiles_); pd.sb_d1 = p.n_ntiles; pd.sb_m1 = td_magic(p.n_ntiles); pd.sb_m2 = td_magic(p.tiles_x); pd.sb_m3 = td_magic(p.tiles_y);
+        pd.sb_grid = grid; pd.sb_grid8 = (grid & 7) == 0 ? (unsigned)grid >> 3 : 0u;
+    }
     auto kern = dma ? conv_glds_kernel<T, TH, TW, NIMG, BN, WAVES_M, WAVES_N, HAS_DMA> : conv_glds_kernel<T, TH, TW, NIMG, BN, WAVES_M, WAVES_N, false>;
     // per (instantiation, device): hipFuncSetAttribute applies to the CURRENT device's copy of the kernel only
     static bool attr_set[2][64] = {};

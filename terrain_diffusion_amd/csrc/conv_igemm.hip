@@ -329,7 +329,20 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
 #pragma unroll
             for (int u = 0; u < 8; ++u) v += t[u];
         }
-        for (; k < p.ksplit; ++k) v += *(const f32x4*)(base + (size_t)k * kstride);
+        if (k + 4 <= p.ksplit) {   // tails of 4 and 2 in flight together as well (ksplit = 9 used to be 8 + 1 round trips, 3 was 3)
+            f32x4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = *(const f32x4*)(base + (size_t)(k + u) * kstride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v += t[u];
+            k += 4;
+        }
+        if (k + 2 <= p.ksplit) {
+            const f32x4 t0 = *(const f32x4*)(base + (size_t)k * kstride), t1 = *(const f32x4*)(base + (size_t)(k + 1) * kstride);
+            v += t0; v += t1;
+            k += 2;
+        }
+        if (k < p.ksplit) v += *(const f32x4*)(base + (size_t)k * kstride);
         ss = epilogue4<T>(p, n, y, x, co, v, rn, aux);
     }
     if (p.out_sumsq) {

@@ -7,7 +7,7 @@
 //     the residual operand of the epilogue is prefetched during the last taps.
 //   * PING-PONG: the two waves that share a SIMD alternate roles every half tap.  One issues its 16 MFMAs of the tap back to back at raised
 //     priority while its partner reads its next fragments from LDS, issues its share of the weight DMA and does the tile epilogue / patch
-//     staging work; a workgroup barrier swaps the roles (both waves run the same code, one a phase behind the other).  The matrix pipe of each SIMD sees one uninterrupted MFMA stream (tools/pp_bench.hip: 1028 cycles per 1024-cycle tap,
+//     staging work; a workgroup barrier swaps the roles (both waves run the same code, one a phase behind the other).  The matrix pipe of each SIMD sees one uninterrupted MFMA stream (profiles/r02_tap_schedule_microbench.txt: 1028 cycles per 1024-cycle tap,
 //     against 1107 for the interleaved schedule with all operands resident in LDS).
 //   * XCD-aware work order: the cout-tile siblings of a pixel tile are taken in the same step by neighbouring workgroups of ONE XCD, so the
 //     halo patch is read from HBM once and from that XCD's L2 by the siblings.

@@ -52,8 +52,6 @@ __global__ __launch_bounds__(256) void sb_repack_kernel(const u32x4* __restrict_
 template <typename V> __device__ __forceinline__ V sb_gld(const void* q) { return *(const __attribute__((address_space(1))) V*)q; }
 template <typename V> __device__ __forceinline__ void sb_gst(void* q, V v) { *(__attribute__((address_space(1))) V*)q = v; }
 
-// exact a / d for a < 2^32 / d with M = ceil(2^32 / d) (host: sb_magic); d == 1 has no 32-bit M
-__device__ __forceinline__ unsigned sb_udiv(unsigned a, unsigned d, unsigned M) { return d == 1 ? a : __umulhi(a, M); }
 // src_pixel of conv_common.h without branches: resample 0 keep, 1 down (src[2y, 2x]), 2 up (src[y/2, x/2])
 __device__ __forceinline__ int sb_src_pixel(int n, int y, int x, int Hs, int Ws, int dn, int up) { return (n * Hs + ((y << dn) >> up)) * Ws + ((x << dn) >> up); }
 
@@ -104,12 +102,12 @@ __global__ __launch_bounds__(256, 2) void conv_sb_kernel(const ConvParams p) {
     // logical id -> (cout tile, pixel tile).  sb_order 0: the cout tiles of a pixel tile are adjacent (they share the halo patch in an XCD's L2),
     // 1: the pixel tiles of a cout tile are adjacent (an XCD's L2 then holds few cout tiles' weights).  Divisions by host-made magic numbers.
     // split-K over workgroups (k_ks > 1, the weight-streaming-bound deep levels at batch 1: see the planner): slice ksp is the outermost index
-    const unsigned ksp = k_ks > 1 ? sb_udiv(bid, k_d0, k_m0) : 0u;
+    const unsigned ksp = k_ks > 1 ? td_udiv(bid, k_d0, k_m0) : 0u;
     bid -= ksp * k_d0;
-    const unsigned q1 = sb_udiv(bid, k_d1, k_m1), r1 = bid - q1 * k_d1;
+    const unsigned q1 = td_udiv(bid, k_d1, k_m1), r1 = bid - q1 * k_d1;
     const unsigned ntile = k_order ? q1 : r1, mtile = k_order ? r1 : q1;
-    const unsigned q2 = sb_udiv(mtile, (unsigned)k_tx, k_m2), txi = mtile - q2 * (unsigned)k_tx;
-    const int n0 = (int)sb_udiv(q2, (unsigned)k_ty, k_m3), tyi = (int)(q2 - (unsigned)n0 * (unsigned)k_ty);
+    const unsigned q2 = td_udiv(mtile, (unsigned)k_tx, k_m2), txi = mtile - q2 * (unsigned)k_tx;
+    const int n0 = (int)td_udiv(q2, (unsigned)k_ty, k_m3), tyi = (int)(q2 - (unsigned)n0 * (unsigned)k_ty);
     const int y0 = tyi * TH, x0 = (int)txi * TW, co0 = (int)ntile * (NT * 32);
     const int NCT = k_cpad / 32, n3 = k_n3;
     // K-groups of this workgroup: [g_lo, g_hi) (everything without split-K; conv_set_kbounds slices balanced by K-steps otherwise): the 3x3 groups
@@ -471,8 +469,6 @@ __global__ __launch_bounds__(256, 2) void conv_sb_kernel(const ConvParams p) {
 #endif
 }
 
-static inline unsigned sb_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((((unsigned long long)1 << 32) + d - 1) / d); }
-
 template <typename T, int TH, int TW, int NT>
 static hipError_t launch_sb_cfg(const ConvParams& p, hipStream_t st) {
     constexpr int MT = TH * TW / 32, NPATCH = (TH + 2) * (TW == 8 ? 12 : TW + 2);
@@ -489,8 +485,8 @@ static hipError_t launch_sb_cfg(const ConvParams& p, hipStream_t st) {
     const int mtiles = p.tiles_x * p.tiles_y * p.img_groups, grid1 = p.n_ntiles * mtiles, grid = grid1 * p.ksplit;
     if (grid1 <= 0 || (long long)grid * std::max(grid1, std::max(mtiles, p.n_ntiles)) >= ((long long)1 << 32)) return hipErrorInvalidValue;   // sb_udiv's range
     ConvParams q = p;
-    q.sb_d0 = grid1; q.sb_m0 = sb_magic(grid1);
-    q.sb_d1 = p.sb_order ? mtiles : p.n_ntiles; q.sb_m1 = sb_magic(q.sb_d1); q.sb_m2 = sb_magic(p.tiles_x); q.sb_m3 = sb_magic(p.tiles_y);
+    q.sb_d0 = grid1; q.sb_m0 = td_magic(grid1);
+    q.sb_d1 = p.sb_order ? mtiles : p.n_ntiles; q.sb_m1 = td_magic(q.sb_d1); q.sb_m2 = td_magic(p.tiles_x); q.sb_m3 = td_magic(p.tiles_y);
     q.sb_grid8 = (grid & 7) == 0 ? (unsigned)grid >> 3 : 0u;
     auto kern = conv_sb_kernel<T, TH, TW, NT>;
     if (lds > 65536) {

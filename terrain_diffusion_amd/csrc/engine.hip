@@ -944,7 +944,7 @@ static int compute_cvecs(td_unet* u, Plan& pl, const std::vector<float>& t_steps
     }
     HIP_TRY(hipMemcpyAsync(pl.tsteps->p, t_steps.data(), t_steps.size() * 4, hipMemcpyHostToDevice, st));
     const int half = u->noise_dims / 2;
-    hipLaunchKernelGGL(emb_kernel, dim3(rows), dim3(256), (size_t)(2 * half + u->embd.feat_total) * 4, st, (const float*)pl.tsteps->p, d_cond, pl.N,
+    hipLaunchKernelGGL(emb_kernel, dim3(rows, (u->emb_ch + 63) / 64), dim3(256), (size_t)(2 * half + u->embd.feat_total) * 4, st, (const float*)pl.tsteps->p, d_cond, pl.N,
                        (const float*)u->d_freqs->p, half, (const float*)u->d_wnoise->p, (const float*)u->d_wcond->p, (const float*)u->d_fourier->p,
                        u->embd, u->emb_ch, (float*)pl.emb->p);
     int max_cout = 64;

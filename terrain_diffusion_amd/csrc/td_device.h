@@ -90,7 +90,8 @@ struct ConvParams {
     const void* wpack_sb;
     int sb_n3;            // number of leading 3x3 K-groups (every 3x3 segment precedes every 1x1 segment)
     int sb_order;         // workgroup order (speed only): 0 = cout tiles of a pixel tile adjacent, 1 = pixel tiles of a cout tile adjacent
-    unsigned sb_d0, sb_m0, sb_d1, sb_m1, sb_m2, sb_m3, sb_grid8;   // launcher-made: first divisor of the workgroup-id decomposition, the magic multipliers (sb_udiv), grid / 8 (0 if 8 does not divide it)
+    unsigned sb_d0, sb_m0, sb_d1, sb_m1, sb_m2, sb_m3, sb_grid8, sb_grid;   // (conv_glds.hip uses the same fields: d0 = pixel tiles, d1 = cout tiles, grid)
+// launcher-made: first divisor of the workgroup-id decomposition, the magic multipliers (sb_udiv), grid / 8 (0 if 8 does not divide it)
 };
 
 // Split-K slice boundaries.  Uniform K-groups: the floor split s*kgroups/ksplit.  A mix of 3x3 and 1x1 groups (the decoder's conv_res1: 3x3 conv

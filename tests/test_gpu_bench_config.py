@@ -79,9 +79,12 @@ LAYERS = ["enc.512x512_conv", "enc.512x512_block0.conv_res0", "enc.512x512_block
 def _forward_with(eng, m, x, t, c, n, **opts):
     prev = {}
     try:
+        # the arms of these tests compare tile shapes of the LDS-DMA conv (conv_glds): the small-batch flavour (round 4, conv_sb.hip -- its own tile
+        # hooks are sb_mt / sb_nt, tests/test_gpu_small_batch.py) would otherwise take the small grids of a batch <= 8 whatever the glds_* hooks say
+        opts = dict(opts, sb=opts.get("sb", 0))
         for k, v in opts.items():
             eng.set_option(k, v)
-            prev[k] = {"glds_variant": -1, "glds_bn": 0, "pp": 0, "glds_splitk": 1, "glds_dma1x1": 1}[k]
+            prev[k] = {"glds_variant": -1, "glds_bn": 0, "pp": 0, "glds_splitk": 1, "glds_dma1x1": 1, "sb": 1}[k]
         eng.set_option("profile", 1)
         eng.profile_read(reset=True)
         y = m(x, t, [c])
@@ -144,14 +147,14 @@ def test_conv_1x1_dma_ragged_tiles_bit_identical_and_vs_oracle(td, base, n, hw, 
     ys = {}
     try:
         for o in (0, 1):
-            eng.set_option("glds_splitk", splitk); eng.set_option("glds_dma1x1", o)
+            eng.set_option("glds_splitk", splitk); eng.set_option("glds_dma1x1", o); eng.set_option("sb", 0)   # conv_glds' own split-K + 1x1 paths
             eng.set_option("profile", 1); eng.profile_read(reset=True)
             ys[o] = m(x, t, [c]).clone()
             labels = [l for l, _, _ in eng.profile_ops()]
             eng.profile_read(reset=True); eng.set_option("profile", 0)
             assert any(" f2" in l and "conv_res1" in l and l.startswith("dec.") for l in labels), labels[:5]
     finally:
-        eng.set_option("glds_splitk", 1); eng.set_option("glds_dma1x1", 1); eng.set_option("profile", 0)
+        eng.set_option("glds_splitk", 1); eng.set_option("glds_dma1x1", 1); eng.set_option("profile", 0); eng.set_option("sb", 1)
     assert torch.equal(ys[0], ys[1]), float((ys[0] - ys[1]).abs().max())
     with torch.no_grad():
         ref = om(x[:1].cpu(), t[:1], [c[:1].cpu()])

@@ -11,7 +11,6 @@
 #include "conv_igemm.hip"
 #include "conv_glds.hip"
 #include "conv_pp.hip"
-#include "experiments/conv_ps.hip"
 using namespace td;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 __global__ void __launch_bounds__(256) bench_prefetch_kernel(const uint4* __restrict__ w, size_t n16, uint4* sink) {
@@ -54,7 +53,7 @@ int main(int argc, char** argv) {
         p.nseg = 2; p.seg[1].src = x2; p.seg[1].C = Cin2; p.seg[1].cstride = Cin2; p.seg[1].Hs = H; p.seg[1].Ws = W; p.seg[1].taps = taps2; p.seg[1].xform = 0; p.seg[1].scale = 1.f;
     }
     p.dma1x1 = getenv("TD_DMA1X1") ? atoi(getenv("TD_DMA1X1")) : 1;
-    bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4 || flavor == 6) ? 4 : 2) : 1; int TH = flavor == 8 ? 4 : ((flavor == 2 || flavor == 4 || flavor == 5 || flavor == 6) && !narrow) ? 16 : 8;  // flavor 8 = conv_glds variant 2 (tiny tile)
+    bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4) ? 4 : 2) : 1; int TH = flavor == 8 ? 4 : ((flavor == 2 || flavor == 4 || flavor == 5) && !narrow) ? 16 : 8;  // flavor 8 = conv_glds variant 2 (tiny tile)
     p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH; p.img_groups = (N + NIMG - 1) / NIMG; p.n_ntiles = Cout / bn;
     p.epi = epi; p.out = out; p.out_cstride = Cout;
     { void* z; CK(hipMalloc(&z, 4096)); CK(hipMemset(z, 0, 4096)); p.zeros = z; }
@@ -69,7 +68,7 @@ int main(int argc, char** argv) {
     if (getenv("TD_EXTRA_LDS")) g_bench_extra_lds = atoi(getenv("TD_EXTRA_LDS"));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto L = [&](const ConvParams& q) { return flavor == 8 ? launch_conv_glds(q, 1, narrow, bn, 2, st) : flavor >= 6 ? launch_conv_ps(q, 1, narrow, bn, flavor - 6, 256, st) : flavor == 5 ? launch_conv_pp(q, 1, bn, 256, st) : flavor >= 2 ? launch_conv_glds(q, 1, narrow, bn, flavor - 2, st) : launch_conv(q, 1, narrow, bn, flavor, st); };
+    auto L = [&](const ConvParams& q) { return flavor == 8 ? launch_conv_glds(q, 1, narrow, bn, 2, st) : flavor == 5 ? launch_conv_pp(q, 1, bn, 256, st) : flavor >= 2 ? launch_conv_glds(q, 1, narrow, bn, flavor - 2, st) : launch_conv(q, 1, narrow, bn, flavor, st); };
     for (int i = 0; i < 4; ++i) CK(L((chain && (i & 1)) ? p2 : p));
     CK(hipStreamSynchronize(st));
     const int reps = 20;
@@ -90,28 +89,6 @@ int main(int argc, char** argv) {
     double flop = 2.0 * M * Cout * ((double)Cin * taps + (double)Cin2 * taps2);
     printf("N%d %dx%d Cin%d Cout%d taps%d xform%d bn%d ks%d fl%d epi%d stg%d ch%d : %.1f us  %.1f TFLOP/s (%.1f%% of 2500)  wgs=%d\n", N, H, W, Cin, Cout, taps, xform, bn, ksplit, flavor, epi, stagger, chain, ms * 1e3,
            flop / ms / 1e9, flop / ms / 1e9 / 25.0, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * ksplit);
-#ifndef TD_TRACE
-    if (flavor >= 6 && flavor < 8) {  // bit-exactness of the persistent-stream flavour against conv_glds with the same tile shape
-        std::vector<uint16_t> o5(M * Cout), o2(M * Cout), q5, q2;
-        std::vector<float> s5, s2;
-        const ConvParams& pp_ = p;
-        CK(hipMemset(pp_.out, 0, M * Cout * 2)); if (pp_.out2) CK(hipMemset(pp_.out2, 0, M * Cout * 2)); if (pp_.out_sumsq) CK(hipMemset(pp_.out_sumsq, 0, M * (Cout / 32) * 4));
-        CK(launch_conv_ps(pp_, 1, narrow, bn, flavor - 6, 256, st)); CK(hipStreamSynchronize(st));
-        CK(hipMemcpy(o5.data(), pp_.out, o5.size() * 2, hipMemcpyDeviceToHost));
-        if (pp_.out2) { q5.resize(M * Cout); CK(hipMemcpy(q5.data(), pp_.out2, q5.size() * 2, hipMemcpyDeviceToHost)); }
-        if (pp_.out_sumsq) { s5.resize(M * (Cout / 32)); CK(hipMemcpy(s5.data(), pp_.out_sumsq, s5.size() * 4, hipMemcpyDeviceToHost)); }
-        CK(hipMemset(pp_.out, 0, M * Cout * 2)); if (pp_.out2) CK(hipMemset(pp_.out2, 0, M * Cout * 2)); if (pp_.out_sumsq) CK(hipMemset(pp_.out_sumsq, 0, M * (Cout / 32) * 4));
-        CK(launch_conv_glds(pp_, 1, narrow, bn, flavor - 6, st)); CK(hipStreamSynchronize(st));
-        CK(hipMemcpy(o2.data(), pp_.out, o2.size() * 2, hipMemcpyDeviceToHost));
-        if (pp_.out2) { q2.resize(M * Cout); CK(hipMemcpy(q2.data(), pp_.out2, q2.size() * 2, hipMemcpyDeviceToHost)); }
-        if (pp_.out_sumsq) { s2.resize(M * (Cout / 32)); CK(hipMemcpy(s2.data(), pp_.out_sumsq, s2.size() * 4, hipMemcpyDeviceToHost)); }
-        size_t bad = 0, first = 0; for (size_t i = 0; i < o5.size(); ++i) if (o5[i] != o2[i]) { if (!bad) first = i; ++bad; }
-        size_t badq = 0; for (size_t i = 0; i < q5.size(); ++i) if (q5[i] != q2[i]) ++badq;
-        size_t bads = 0; for (size_t i = 0; i < s5.size(); ++i) if (memcmp(&s5[i], &s2[i], 4)) ++bads;
-        size_t nz = 0; for (auto v : o2) nz += (v & 0x7fff) != 0;
-        printf("  check vs conv_glds: %zu / %zu outputs differ (first at %zu: pixel %zu cout %zu), out2 diffs %zu, sumsq diffs %zu, nonzero outputs %zu\n", bad, o5.size(), first, first / Cout, first % Cout, badq, bads, nz);
-    }
-#endif
     if (Cin2 && (flavor == 2 || flavor == 3 || flavor == 8)) {  // register-staged vs LDS-DMA 1x1 path of conv_glds: same K order, same MFMA -> same bits
         std::vector<uint16_t> o0(M * Cout), o1(M * Cout);
         for (int d = 0; d < 2; ++d) {
@@ -154,8 +131,7 @@ int main(int argc, char** argv) {
 #endif
 #ifdef TD_TRACE
     {
-        int wgs = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups; const int nw = flavor == 4 ? 12 : ((flavor == 3 || flavor == 7) ? 4 : 8), TS = 16;
-        if (flavor >= 6) { int g = flavor == 7 ? 512 : 256; while (g > 8 && g - 8 >= wgs) g -= 8; wgs = g; }  // persistent grid  // waves per workgroup of the variant, u64 per wave record
+        int wgs = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups; const int nw = flavor == 4 ? 12 : (flavor == 3 ? 4 : 8), TS = 16;
         std::vector<unsigned long long> tb((size_t)wgs * nw * TS);
         CK(hipMemcpy(tb.data(), partial, tb.size() * 8, hipMemcpyDeviceToHost));
         double s[5] = {0, 0, 0, 0, 0}; unsigned long long t0 = ~0ull, t1 = 0;
@@ -175,8 +151,6 @@ int main(int argc, char** argv) {
         printf("  trace (s_memtime ticks, mean per wave): prologue %.0f  loop %.0f (of which tap-entry wait %.0f, restage %.0f, body %.0f)  epilogue %.0f  | WG total %.0f | kernel span %.0f ticks = %.2f ticks/us\n",
                s[0], s[1], s[3], s[4], s[1] - s[3] - s[4], s[2], s[0] + s[1] + s[2], (double)(t1 - t0), (double)(t1 - t0) / (ms * 1e3));
         printf("  taps per WG: %d  -> body %.0f ticks/tap, wait %.0f ticks/tap\n", ksteps, (s[1] - s[3] - s[4]) / ksteps, s[3] / ksteps);
-        if (flavor >= 6) { double it = 0, pro = 0, adv = 0; for (int i = 0; i < wgs * nw; ++i) { it += (double)tb[(size_t)i * TS + 11]; pro += (double)tb[(size_t)i * TS + 12]; adv += (double)tb[(size_t)i * TS + 13]; }
-            printf("  persistent: %.2f items per wave; first prologue %.0f ticks, cursor advance %.0f ticks in total; per item: taps+restage %.0f, epilogue %.0f, advance %.0f\n", it / (wgs * nw), pro / (wgs * nw), adv / (wgs * nw), s[1] / (it / (wgs * nw)), s[2] / (it / (wgs * nw)), adv / it); }
         { double dr = 0; for (int i = 0; i < wgs * nw; ++i) dr += (double)tb[(size_t)i * TS + 11]; printf("  of the epilogue: %.0f ticks waiting for the stores to drain after the last one was issued\n", dr / ((double)wgs * nw)); }
     }
 #endif

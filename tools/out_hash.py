@@ -6,6 +6,9 @@ import terrain_diffusion_amd as td
 from terrain_diffusion_amd._lib import lib
 from oracle.unet import BASE_CONFIG, synth_state_dict
 from oracle import rng
+for kv in os.environ.get("TD_OPTS", "").split(","):
+    if kv:
+        k, v = kv.split("="); td.engine.get_engine("cuda").set_option(k, int(v))
 cfg = dict(BASE_CONFIG)
 m = td.EDMUnet2D(**cfg, dtype="bf16").load_state_dict(synth_state_dict(cfg, seed=1234))
 hs = []
