@@ -18,6 +18,7 @@ Weights are synthetic (portable-RNG seeded, out_gain=1, emb_gain=0.5): there is 
 """
 import argparse
 import json
+import re
 import os
 import socket
 import subprocess
@@ -102,8 +103,10 @@ def main():
 
     dev = f"cuda:{local_rank}"
     eng = get_engine(dev)
+    eng_opts = {}
     for kv in filter(None, args.engine_opts.split(",")):
         k_, v_ = kv.split("=")
+        eng_opts[k_] = int(v_)
         eng.set_option(k_, int(v_))
     if workload == "cascade":
         from terrain_diffusion_amd.cascade_bench import run_cascade
@@ -211,10 +214,15 @@ def main():
             one_step(10_000)
             sync()
             g_ms, g_flop, g_n = eng.profile_read_glds(reset=True)
+            sb_rows = [(float(re.search(r" gf([0-9.]+)", l_).group(1)), ms_, n_) for l_, ms_, n_ in eng.profile_ops() if re.search(r" f4\w* bn", l_)]
             conv_ms, conv_n, other_ms, other_n = eng.profile_read(reset=True)
             eng.set_option("profile", 0)
             roof.update({"all_conv_kernels_ms_per_step": round(conv_ms, 3), "all_conv_launches_per_step": conv_n,
                          "other_unet_kernel_ms_per_step": round(other_ms, 3)})
+            if sb_rows:   # round 4: the launches whose grid does not fill the chip (the 8x8 level at batch 64) run on the small-batch flavour
+                sb_ms = sum(ms_ for _, ms_, _ in sb_rows); sb_gf = sum(gf_ * n_ for gf_, _, n_ in sb_rows)
+                roof["small_batch_kernel"] = {"kernel": "td::conv_sb_kernel", "launches_per_step": sum(n_ for _, _, n_ in sb_rows), "kernel_ms_per_step": round(sb_ms, 3),
+                                              "achieved": round(sb_gf / sb_ms, 2) if sb_ms > 0 else None, "unit": "TFLOP/s"}
             if g_n > 0:   # dominant kernel family: the LDS-DMA implicit-GEMM conv (terrain_diffusion_amd/csrc/conv_glds.hip / conv_pp.hip)
                 ach = g_flop / (g_ms * 1e-3) / 1e12
                 dual_on = "dual_stream=1" in args.engine_opts or (strong and "dual_stream=0" not in args.engine_opts)
@@ -275,12 +283,16 @@ def main():
             result["single_tile_mp_per_s"] = round(0.262144 / lat, 3)
             hbm = E * WEIGHT_BYTES_BF16 / lat / 1e9
             result["roofline_single_tile"] = {"bound": "hbm", "achieved": round(hbm, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(hbm / PEAK_HBM_GBS, 4),
-                                              "note": f"algorithmic bytes = {E} forwards x {WEIGHT_BYTES_BF16} B of bf16 weights (activations of one tile are negligible)"}
+                                              "kernel": "td::conv_sb_kernel (small-batch flavour: K split over the waves of a workgroup, no fp32 partial planes in HBM "
+                                                        "above the 16x16 level) + td::conv_splitk_reduce_kernel behind the 8x8 / 16x16 levels",
+                                              "note": f"algorithmic bytes = {E} forwards x {WEIGHT_BYTES_BF16} B of bf16 weights (activations of one tile are negligible); "
+                                                      "measured HBM bytes per forward: profiles/r04_batch_sweep.txt"}
 
         if world == 1 and not args.no_latency and workload == "grid8" and args.dtype == "bf16":
             # N = 1 point of the STRONG-scaling workload the driver runs at N > 1 (grid32, BASELINE configs[3]): one full step, timed live in this
             # run with the same engine options the sharded run uses, so that the 1 -> N curve has a same-run, same-node anchor
             from terrain_diffusion_amd.parallel import sample_base_diffusion_sharded
+            prev_opts = {k_: eng_opts.get(k_, 0) for k_ in ("batch_invariant", "dual_stream")}   # what --engine-opts asked for, restored afterwards
             eng.set_option("batch_invariant", 1); eng.set_option("dual_stream", 1)
             try:
                 one_step(30_000, 64, "tiles"); sync()          # builds the batch-invariant plans and graphs of the two 32-window lanes
@@ -295,7 +307,8 @@ def main():
                                                    "value": round(mp32 / adt, 4), "unit": "MP/s", "ms_per_step": round(adt * 1e3, 2), "steps_timed": 1,
                                                    "note": "divide an N > 1 driver line's value by N x this to get the strong-scaling efficiency of that workload"}
             finally:
-                eng.set_option("batch_invariant", 0); eng.set_option("dual_stream", 0)
+                for k_, v_ in prev_opts.items():
+                    eng.set_option(k_, v_)
 
         if world == 1 and not args.no_cpu_baseline:
             # CPU baseline = the oracle (CPU restatement pinned to the reference) on this host's cores, bounded sample

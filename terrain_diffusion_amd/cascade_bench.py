@@ -39,11 +39,14 @@ def run_cascade(args, eng, dev, rank, world):
     cache = int(getattr(args, 'cache_mib', 100)) * 2 ** 20   # default 100 MiB = the reference's cache_limit (world_pipeline.py:311); one step produces ~150 MiB of windows -> streaming eviction
     world_p = td.WorldPipeline.from_models(*models, seed=4242, dtype=dtype, device=dev, cache_limit=cache, latents_batch_size=(1, 2, 4, 8, 16, 32, 64)).bind()
 
+    split = {}
+
     def one_step(i):
         i0, j0 = 100_000 * (i + 1), -50_000 * (i + 1)
         out = None
         boxes = [(i0 + a, j0 + b, i0 + a + Q, j0 + b + Q) for a in range(0, R, Q) for b in range(0, R, Q)]
         mine = [bx for _, bx in shard_requests(boxes, world, rank)] if world > 1 else boxes
+        split["requests_this_rank"] = len(mine); split["requests_per_step"] = len(boxes)
         for bx in mine:
             out = world_p.get(*bx)
         return out
@@ -70,6 +73,25 @@ def run_cascade(args, eng, dev, rank, world):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert out is None or bool(torch.isfinite(out["elev"]).all())
+    per_rank = [split.get("requests_this_rank", 0)]
+    if world > 1:   # the request split of the replica mode, rank by rank (make the N > 1 cascade line say who served what)
+        pr = torch.zeros(world, dtype=torch.int64, device=dev); pr[rank] = per_rank[0]
+        dist.all_reduce(pr)
+        per_rank = [int(v) for v in pr.tolist()]
+    # the regime between the two legs the driver line reports (batch 1 and batch 64): the base U-Net's forward at the batch sizes the latent stage
+    # actually runs (latents_batch_size 1 ... 64), wall time per forward of eager launches on the engine stream
+    sweep = {}
+    if rank == 0:
+        base = models[1]
+        for nb in (1, 8, 32):
+            x = td.standard_normal(7, (nb, 5, 64, 64), device=dev, as_torch=True); c = td.standard_normal(8, (nb, 58), device=dev, as_torch=True); tt_ = torch.full((nb,), 1.1)
+            base(x, tt_, [c]); sync()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                base(x, tt_, [c])
+            sync()
+            ms_f = (time.perf_counter() - t1) / 5 * 1e3
+            sweep[str(nb)] = {"ms_per_forward": round(ms_f, 3), "tflops": round(nb * 193.654 / ms_f, 1)}
     mp = R * R / 1e6
     value = args.steps * mp / dt
     # per-stage kernel time: one profiled (eager) request of fresh terrain
@@ -100,7 +122,10 @@ def run_cascade(args, eng, dev, rank, world):
                                "(streaming eviction)",
                    "decoded_mp_per_step": mp, "parallelism": (f"{world} ranks, request-replica mode: one world, requests dealt in Z-curve order, no data-path collective" if world > 1 else "1 rank"), "windows_per_step": {k: round(t.windows_computed / args.steps, 1) for k, t in
                                                                    (("coarse", world_p.coarse), ("latent_final_phase", world_p.latents), ("decoder", world_p.residual))},
-                   "cache_evictions_per_step": round((world_p.tile_store.evictions - ev0) / args.steps, 1)},
+                   "cache_evictions_per_step": round((world_p.tile_store.evictions - ev0) / args.steps, 1),
+                   "requests_per_step": split.get("requests_per_step"), "requests_per_rank": per_rank},
+        "batch_sweep": {"what": "base U-Net forward (193.654 GFLOP per tile) at the latent stage's batch sizes, eager launches, wall ms per forward; "
+                                "the full 1 ... 64 sweep with HBM bytes is profiles/r04_batch_sweep.txt", "by_batch": sweep},
         "roofline": {"bound": "mfma", "kernel": "td::conv_glds_kernel (all stages)", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "achieved": round(tflops, 2),
                      "frac": round(tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
                      "note": "end to end over the algorithmic 15.24 TFLOP per decoded MP (recomputed evicted windows are NOT counted as useful work)",

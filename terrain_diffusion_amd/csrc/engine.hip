@@ -229,6 +229,7 @@ struct Plan {
     std::vector<float> graph_sigmas;
     float graph_sigma_data = 0.f;
     int graph_solver_order = 0;
+    int graph_lof = -1;        // engine option "lower_order_final" the graph was captured under
     int graph_fuse = -1;       // engine option "fuse_solver" the graph was captured under
     const void* graph_guide = nullptr;       // guide plan / its modulation buffer / scale the captured graph was built with (autoguidance)
     const void* graph_guide_cvec = nullptr;
@@ -921,7 +922,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
     HIP_TRY(pl.x->alloc(xbytes)); HIP_TRY(pl.m1->alloc(xbytes)); HIP_TRY(pl.m2->alloc(xbytes)); HIP_TRY(pl.xt->alloc(xbytes));
     HIP_TRY(pl.cond->alloc((size_t)N * std::max(1, u->cond_row_len) * 4));
     HIP_TRY(hipDeviceSynchronize());  // buffer memsets ran on the null stream; the engine stream is non-blocking
-    pl.bytes += 3 * xbytes;
+    pl.bytes += 4 * xbytes + (size_t)N * std::max(1, u->cond_row_len) * 4;   // x, m1, m2, xt (+ cond): what the plan-cache budget has to see
     pl.last_use = ++u->use_clock;
     *out = plp.get();
     u->plans[key] = std::move(plp);
@@ -943,6 +944,9 @@ static int compute_cvecs(td_unet* u, Plan& pl, const std::vector<float>& t_steps
         pl.cvec_rows = rows;
     }
     HIP_TRY(hipMemcpyAsync(pl.tsteps->p, t_steps.data(), t_steps.size() * 4, hipMemcpyHostToDevice, st));
+    // `t_steps` lives on the caller's stack: with option "async" the call may return before the stream gets here, so the (80-byte) upload is
+    // waited for now rather than relying on the runtime staging pageable sources synchronously
+    if (u->eng->option("async", 0) != 0) HIP_TRY(hipStreamSynchronize(st));
     const int half = u->noise_dims / 2;
     hipLaunchKernelGGL(emb_kernel, dim3(rows, (u->emb_ch + 63) / 64), dim3(256), (size_t)(2 * half + u->embd.feat_total) * 4, st, (const float*)pl.tsteps->p, d_cond, pl.N,
                        (const float*)u->d_freqs->p, half, (const float*)u->d_wnoise->p, (const float*)u->d_wcond->p, (const float*)u->d_fourier->p,
@@ -1022,7 +1026,7 @@ static int run_unet(td_unet* u, Plan& pl, int step, const SchedCoef* fuse = null
             mb_ *= 1e-6;
             snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f mb%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 4 ? (op.sb_mt == 2 ? (op.sb_nt == 2 ? "m2n2" : "m2n1") : (op.sb_nt == 2 ? "m1n2" : "m1n1")) : op.flavor == 3 ? "p" : op.flavor == 2 ? (op.glds_variant == 2 ? "t" : op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_, mb_); ev_label.push_back(op.label + tag);
             double kk = 0; for (int s_ = 0; s_ < p.nseg; ++s_) kk += (double)p.seg[s_].C * p.seg[s_].taps;
-            ev_flop.push_back(op.flavor >= 2 ? 2.0 * p.N * p.H * p.W * (double)p.Cout * kk : 0.0); }
+            ev_flop.push_back((op.flavor == 2 || op.flavor == 3) ? 2.0 * p.N * p.H * p.W * (double)p.Cout * kk : 0.0); }   // the LDS-DMA family alone (bench.py's roofline kernel); small-batch launches are told apart by their f4 label
         if (e != hipSuccess) return fail(TD_ERR_HIP, "conv launch " + op.label + ": " + hipGetErrorString(e));
     }
     return TD_OK;
@@ -1252,7 +1256,7 @@ int td_unet_read_activation(td_unet* u, int n, int H, int W, const char* label, 
 
 // ---- schedule: the Karras sigma ladder is computed by the host scheduler with the reference's own fp32 torch ops (bit-exact,
 // terrain_diffusion_amd/scheduler.py); the engine receives the sigmas and derives the per-step solver coefficients here.
-static void dpm_coefs(const float* sig, int n_steps, float sigma_data, int solver_order, std::vector<SchedCoef>& ks) {
+static void dpm_coefs(const float* sig, int n_steps, float sigma_data, int solver_order, bool lower_order_final, std::vector<SchedCoef>& ks) {
     // fp32 scalar arithmetic in the reference's order (dpmsolver.py:245-258, 472-482, 515-540); order rule :688-715
     ks.resize(n_steps);
     int lower = 0;
@@ -1262,7 +1266,7 @@ static void dpm_coefs(const float* sig, int n_steps, float sigma_data, int solve
         k.c_skip = (sd * sd) / (s * s + sd * sd);
         k.c_out = s * sd / sqrtf(s * s + sd * sd);
         const bool final = (i == n_steps - 1);
-        const bool second = (i == n_steps - 2) && n_steps < 15;   // lower_order_second (dpmsolver.py:694-696; lower_order_final is the released setting)
+        const bool second = (i == n_steps - 2) && lower_order_final && n_steps < 15;   // lower_order_second (dpmsolver.py:694-696), engine option "lower_order_final"
         // dpmsolver.py:703-708 with config.solver_order and lower_order_final
         k.order = (solver_order < 2 || lower < 1 || final) ? 1 : ((solver_order == 2 || lower < 2 || second) ? 2 : 3);
         const float lam_t = 0.f - logf(st), lam_s = 0.f - logf(s);
@@ -1342,7 +1346,8 @@ static int sample_edm_lane(td_unet* u, td_unet* guide, float gscale, int n, int 
     std::vector<SchedCoef> ks;
     const int solver_order = (int)e->option("solver_order", 2);
     if (solver_order < 1 || solver_order > 3) return fail(TD_ERR_ARG, "solver_order must be 1, 2 or 3");
-    dpm_coefs(sigmas_host, n_steps, sigma_data, solver_order, ks);
+    const bool lof = e->option("lower_order_final", 1) != 0;
+    dpm_coefs(sigmas_host, n_steps, sigma_data, solver_order, lof, ks);
     const float c_in0 = 1.f / sqrtf(sigmas_host[0] * sigmas_host[0] + sigma_data * sigma_data);
 
     auto enqueue = [&]() -> int {
@@ -1371,7 +1376,7 @@ static int sample_edm_lane(td_unet* u, td_unet* guide, float gscale, int n, int 
         std::vector<float> sg(sigmas_host, sigmas_host + n_steps + 1);
         // the guide's plan can be evicted / its buffers re-allocated independently of this plan: key the graph on them too
         const void* gkey = gpl ? (const void*)gpl->cvec->p : nullptr;
-        if (!pl->graph || pl->graph_sigmas != sg || pl->graph_sigma_data != sigma_data || pl->graph_solver_order != solver_order ||
+        if (!pl->graph || pl->graph_sigmas != sg || pl->graph_sigma_data != sigma_data || pl->graph_solver_order != solver_order || pl->graph_lof != (int)lof ||
             pl->graph_guide != (const void*)gpl || pl->graph_guide_cvec != gkey || pl->graph_gscale != gscale || pl->graph_fuse != (int)e->option("fuse_solver", 1)) {
             pl->drop_graph();
             hipGraph_t g = nullptr;
@@ -1383,7 +1388,7 @@ static int sample_edm_lane(td_unet* u, td_unet* guide, float gscale, int n, int 
             hipError_t ie = hipGraphInstantiate(&pl->graph, g, nullptr, nullptr, 0);
             (void)hipGraphDestroy(g);
             if (ie != hipSuccess) { pl->graph = nullptr; return fail(TD_ERR_HIP, std::string("graph instantiate: ") + hipGetErrorString(ie)); }
-            pl->graph_sigmas = sg; pl->graph_sigma_data = sigma_data; pl->graph_solver_order = solver_order; pl->graph_fuse = (int)e->option("fuse_solver", 1);
+            pl->graph_sigmas = sg; pl->graph_sigma_data = sigma_data; pl->graph_solver_order = solver_order; pl->graph_lof = (int)lof; pl->graph_fuse = (int)e->option("fuse_solver", 1);
             pl->graph_guide = gpl; pl->graph_guide_cvec = gkey; pl->graph_gscale = gscale;
         }
         HIP_TRY(hipGraphLaunch(pl->graph, st));

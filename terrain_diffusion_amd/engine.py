@@ -59,11 +59,17 @@ class Engine:
             _SHARED_STREAM.pop(self.device_id, None)
 
     def on_stream(self, stream, asynchronous=True):
-        """Context manager: run the engine on `stream`; with asynchronous=True calls on device tensors only enqueue (option "async")."""
+        """Context manager: run the engine on `stream`; with asynchronous=True calls on device tensors only enqueue (option "async").
+        A torch.cuda.Stream is also made torch's CURRENT stream for the duration (the producers of the engine's inputs and the consumers of its
+        outputs must be ordered on that same stream: `ptr()` skips its host synchronisation exactly when torch's current stream is the stream the
+        engine launches on).  With a raw hipStream_t handle the caller is responsible for that ordering.  One Engine per device (get_engine)."""
         eng = self
 
         class _Ctx:
             def __enter__(self_):
+                self_.tctx = torch.cuda.stream(stream) if isinstance(stream, torch.cuda.Stream) else None
+                if self_.tctx is not None:
+                    self_.tctx.__enter__()
                 eng.set_stream(stream)
                 eng.set_option("async", 1 if asynchronous else 0)
                 return eng
@@ -71,6 +77,8 @@ class Engine:
             def __exit__(self_, *exc):
                 eng.set_option("async", 0)
                 eng.set_stream(None)     # drains the stream and releases the staging buffers
+                if self_.tctx is not None:
+                    self_.tctx.__exit__(*exc)
                 return False
         return _Ctx()
 
@@ -97,6 +105,14 @@ def get_engine(device=None) -> Engine:
 
 
 _SHARED_STREAM = {}   # device index -> raw handle of the caller stream the engine currently launches on (Engine.set_stream)
+
+
+def engine_on_current_stream(device) -> bool:
+    """True when the engine of `device` launches on torch's CURRENT stream (Engine.set_stream / on_stream): work enqueued by torch on that
+    stream -- RCCL transfers included -- is then ordered with the engine's kernels by the stream itself and needs no host synchronisation."""
+    d = torch.device(device)
+    idx = d.index if d.index is not None else torch.cuda.current_device()
+    return _SHARED_STREAM.get(idx) == torch.cuda.current_stream(d).cuda_stream
 
 
 def ptr(t):

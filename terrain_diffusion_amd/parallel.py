@@ -115,14 +115,36 @@ def exchange_windows(plan: ShardPlan, rank, my_tiles, group=None):
         for req in dist.batch_isend_irecv(ops):
             req.wait()
         if my_tiles.is_cuda:
-            # RCCL's wait() only orders the transfer before later work on torch's CURRENT stream; the engine blends on its own stream
-            torch.cuda.current_stream(my_tiles.device).synchronize()
+            # RCCL's wait() orders the transfer before later work on torch's CURRENT stream.  The sharded samplers put the engine on that very
+            # stream (_engine_stream below: td_engine_set_stream), so the blend that follows is ordered behind the transfers by the stream itself
+            # and the host never waits; only a caller that left the engine on its own stream still needs the synchronisation.
+            from .engine import engine_on_current_stream
+            if not engine_on_current_stream(my_tiles.device):
+                torch.cuda.current_stream(my_tiles.device).synchronize()
     for s, (buf, wins) in recv_bufs.items():
         if host_stage:
             buf = buf.to(my_tiles.device)
         for i, w in enumerate(wins):
             have[w] = buf[i]
     return have
+
+
+_EXCHANGE_STREAMS = {}
+
+
+def _engine_stream(model):
+    """Context manager for the engine-backed sharded samplers: the engine, torch's tensor glue and the RCCL seam exchange all run on ONE
+    side stream per device (torch's default stream is the legacy NULL stream, which the engine's captured graphs cannot use), so that
+    sample -> exchange -> blend is ordered by the stream and not by host synchronisations.  Engine calls stay synchronous inside (results are
+    complete on return, as everywhere else); leaving the context drains the stream."""
+    import contextlib
+    dev = torch.device(getattr(model, "device", "cpu"))
+    if dev.type != "cuda":
+        return contextlib.nullcontext()
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _EXCHANGE_STREAMS:
+        _EXCHANGE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return model.engine.on_stream(_EXCHANGE_STREAMS[idx], asynchronous=False)
 
 
 def blend_region(plan: ShardPlan, rank, have, blend_fn, normalize_fn, channels, scale):
@@ -166,6 +188,16 @@ def sample_base_diffusion_sharded(model, scheduler, shape, cond_inputs, *, cond_
     """Sharded sample_base_diffusion (terrain_diffusion/training/evaluation/sample_diffusion_base.py:115-168).
     Returns (region_tensor (C,h,w), (y0,y1,x0,x1)) for this rank, or the assembled (1,C,H,W) on rank `gather_to`.
     sample_fn / blend_fn / normalize_fn default to the HIP engine; tests inject CPU stand-ins to exercise the plumbing under gloo."""
+    if sample_fn is None and model is not None and not getattr(_engine_stream, "_inside", False):
+        # engine path: everything below runs on the engine's side stream (see _engine_stream)
+        with _engine_stream(model):
+            _engine_stream._inside = True
+            try:
+                return sample_base_diffusion_sharded(model, scheduler, shape, cond_inputs, cond_means=cond_means, cond_stds=cond_stds, noise_level=noise_level,
+                                                     histogram_raw=histogram_raw, steps=steps, tile_size=tile_size, noise_seed=noise_seed, noise_origin=noise_origin,
+                                                     max_batch=max_batch, group=group, gather_to=gather_to, stats=stats)
+            finally:
+                _engine_stream._inside = False
     B, C_, H, W = shape
     assert B == 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -255,6 +287,15 @@ def sample_base_consistency_sharded(model, scheduler, shape, cond_inputs, *, con
         sample out of that box, so no blended canvas ever crosses a seam, only window outputs do (canonical per-pixel summation order);
       * after the last phase: the region it owns.
     In batch-invariant engine mode the assembled canvas is bit-identical to the one-rank sampler.  Returns like sample_base_diffusion_sharded."""
+    if step_fn is None and model is not None and not getattr(_engine_stream, "_inside", False):
+        with _engine_stream(model):   # engine path: sample -> exchange -> blend of every phase on the engine's side stream
+            _engine_stream._inside = True
+            try:
+                return sample_base_consistency_sharded(model, scheduler, shape, cond_inputs, cond_means=cond_means, cond_stds=cond_stds, noise_level=noise_level,
+                                                       histogram_raw=histogram_raw, intermediate_t=intermediate_t, tile_size=tile_size, noise_seed=noise_seed,
+                                                       noise_origin=noise_origin, max_batch=max_batch, group=group, gather_to=gather_to, stats=stats)
+            finally:
+                _engine_stream._inside = False
     B, C_, H, W = shape
     assert B == 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0

@@ -119,6 +119,9 @@ def sample_tiles_edm(model, scheduler, x, cond, steps, cond_img=None, guide_mode
     scheduler.set_timesteps(steps)
     sig = scheduler.sigmas.to(torch.float32).cpu().contiguous()
     model.engine.set_option("solver_order", int(getattr(scheduler.config, "solver_order", 2)))
+    # dpmsolver.py:694-696: the second-to-last step of a third-order run drops to second order only when config.lower_order_final is set (and the
+    # run has < 15 steps); the engine's order schedule follows the scheduler's flag instead of assuming the released default
+    model.engine.set_option("lower_order_final", int(bool(getattr(scheduler.config, "lower_order_final", True))))
     n, _, H, W = x.shape
     cimg = 0 if cond_img is None else cond_img.shape[1]
     if guide_model is not None and guidance_scale != 1.0:   # autoguidance (sample_diffusion_base.py:105-110)
@@ -371,6 +374,8 @@ def sample_coarse_tiled(model, scheduler, cond_img, cond_snr, *, steps=15, tile_
     assert cond_img.ndim == 4, "cond_img must be [B, C, H, W]"
     b, c_cond, h, w = cond_img.shape
     T, h_starts, w_starts, tile_idx = _tile_geometry(h, w, tile_size, tile_stride, w)
+    if h < T or w < T:   # the reference sizes each tile from its cond slice (sample_coarse.py:88-92); this sampler draws square T x T tiles
+        raise ValueError(f"sample_coarse_tiled: the conditioning image ({h} x {w}) is smaller than the tile ({T} x {T}); pass tile_size <= min(h, w)")
     c_out = int(model.config["out_channels"])
     snr = torch.as_tensor(cond_snr, dtype=torch.float32)
     t_cond = torch.atan(snr)

@@ -55,6 +55,26 @@ def test_attention_vs_reference(B, H, Lq, Lk, D, norm):
     assert e32 < 1.5e-2 and e16 < 4e-3
 
 
+@pytest.mark.parametrize("scale", [0.173, 0.31])
+def test_attention_arbitrary_scale_long_keys_d40(scale):
+    """ADVICE round 3: the kernel folds scale * log2(e) into Q before the bf16 rounding and sums an fp32 denominator against a bf16 numerator;
+    a scale that is not a power of two, head dim 40 (zero-padded to 48) and 4096 keys is where a drift in that normalisation would show."""
+    from terrain_diffusion_amd.attention import attention
+    g = torch.Generator().manual_seed(4040)
+    q, k, v = (torch.randn(1, 2, L, 40, generator=g) * s for L, s in ((512, 1.3), (4096, 0.9), (4096, 2.0)))
+    out = attention(q, k, v, scale=scale).cpu()
+    rb = lambda t: t.bfloat16().float()
+    e32 = rel_rms(out.numpy(), _ref(q, k, v, scale, False).numpy())
+    e16 = rel_rms(out.numpy(), _ref(rb(q), rb(k), rb(v), scale, False).numpy())
+    # the operand the kernel really contracts: Q scaled by scale * log2(e) and THEN rounded to bf16
+    f = scale * 1.4426950408889634
+    e16s = rel_rms(out.numpy(), _ref(rb(q * f) / f, rb(k), rb(v), scale, False).numpy())
+    print(f"attention 512x4096 d40 scale {scale}: rel-RMS {e32:.2e} vs fp32, {e16:.2e} vs bf16-operand reference, {e16s:.2e} vs the reference with Q rounded after scaling")
+    # sharper softmax (logit std ~2.3 at scale 0.31) amplifies operand rounding: 6e-3 against plainly rounded operands; against the operands the
+    # kernel actually uses (Q rounded after scaling) the usual 4e-3 holds -- the gap between the two is the extra rounding the kernel header states
+    assert e32 < 1.5e-2 and e16 < 6e-3 and e16s < 4e-3
+
+
 def test_unet_attention_blocks_use_the_mfma_kernel_and_match():
     """the engine's own attention blocks (bf16 mode) go through the MFMA kernel; option attn_mfma=0 selects the scalar fp32 kernel of round 1:
     the two must agree to bf16 rounding, and 16x16-level attention (256 tokens) -- impossible for the scalar kernel -- runs."""
