@@ -33,7 +33,7 @@ WEIGHT_BYTES_BF16 = 253_688_037 * 2  # algorithmic minimum HBM bytes per forward
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-PROFILE_JSON = os.path.join(ROOT, "profiles", "r03_hbm_traffic_and_mfma_util.json")   # stamped with the library build id it was collected with
+PROFILE_JSON = os.path.join(ROOT, "profiles", "r04_hbm_traffic_and_mfma_util.json")   # stamped with the library build id it was collected with
 
 # terrain-diffusion-30m base model (configs/diffusion_base/30m/diffusion_192-3.cfg:54-68)
 BASE_CONFIG = dict(image_size=512, in_channels=5, out_channels=5, model_channels=192, model_channel_mults=[1, 2, 3, 4], layers_per_block=3,

@@ -462,7 +462,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
 
     TD_T(tr_loop);
     // ---------------- epilogue: lane holds, per 32x32 tile, 4 groups of 4 consecutive couts of pixel column (lane & 31)
-    const size_t M = (size_t)p.N * p.H * p.W;
+    // Its scalar kernel arguments in ONE burst (round 4; hipcc otherwise re-reads them one at a time behind the epilogue's uniform branches:
+    // five serialised scalar-cache round trips between the last MFMA and the first store of every workgroup).  Pointers are not pinned (a
+    // pointer that went through an asm statement would be accessed with FLAT instructions); only their null tests are.
+    int e_of32 = p.out_f32, e_Cout = p.Cout, e_epi = p.epi, e_ocs = p.out_cstride, e_cvs = p.cvec_stride, e_rcs = p.res_cstride, e_rHs = p.res_Hs, e_rWs = p.res_Ws,
+        e_rrs = p.res_resample;
+    float e_rsc = p.res_scale, e_clip = p.clip, e_o2s = p.out2_scale;
+    const bool e_hres = p.res != nullptr, e_hrss = p.res_sumsq != nullptr, e_hoss = p.out_sumsq != nullptr, e_ho2 = p.out2 != nullptr;
+    asm volatile("" : "+s"(e_of32), "+s"(e_Cout), "+s"(e_epi), "+s"(e_ocs), "+s"(e_cvs), "+s"(e_rcs), "+s"(e_rHs), "+s"(e_rWs), "+s"(e_rrs), "+s"(e_rsc), "+s"(e_clip),
+                 "+s"(e_o2s));
+    const size_t M = (size_t)k_N * k_H * k_W;
 #ifdef TD_ABLATE_EPI
     {
         float t_ = 0.f;
@@ -480,15 +489,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
     // lane (l ^ 32) the next 4; one v_permlane32_swap per dword turns two row groups into one 16-byte run per lane, so the tile
     // leaves as dwordx4 stores (the store tail is issue-bound: half the instructions, half the time; guide T21).  The residual is
     // fetched the same way in reverse (16-byte loads, then the same swap restores the MFMA layout).
-    const bool wide = !p.out_f32 && (p.Cout & 7) == 0;
-    if (p.ksplit > 1) {  // raw fp32 partial sums [ksplit][pixel][CoutPad]; conv_splitk_reduce_kernel adds them in fixed order + epilogue
+    const bool wide = !e_of32 && (e_Cout & 7) == 0;
+    if (k_ks > 1) {  // raw fp32 partial sums [ksplit][pixel][CoutPad]; conv_splitk_reduce_kernel adds them in fixed order + epilogue
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             int img, ty, tx;
             frag_pixel<TW, TPIX>(wm * WM + i * 32, l31, img, ty, tx);
             const int n = n0 + img, y = y0 + ty, x = x0 + tx;
-            if (n < p.N && y < p.H && x < p.W) {
-                float* prow = p.partial + ((size_t)ksp * M + ((size_t)n * p.H + y) * p.W + x) * p.CoutPad + co0 + wn * WN + 4 * lh;
+            if (n < k_N && y < k_H && x < k_W) {
+                float* prow = p.partial + ((size_t)ksp * M + ((size_t)n * k_H + y) * k_W + x) * k_cpad + co0 + wn * WN + 4 * lh;
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -503,35 +512,35 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
         int img, ty, tx;
         frag_pixel<TW, TPIX>(wm * WM + i * 32, l31, img, ty, tx);
         const int n = n0 + img, y = y0 + ty, x = x0 + tx;
-        const bool ok = n < p.N && y < p.H && x < p.W;
+        const bool ok = n < k_N && y < k_H && x < k_W;
         // sums of squares (pixel-norm statistic of the consumer) are kept per 32-cout MFMA block: the partial decomposition -- and with it
         // the fp32 summation order the consumer sees -- is then the same for every tile shape (bn 96 / 128, 4 or 8 waves, ping-pong)
         float ssj[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) ssj[j] = 0.f;
         if (ok) {
-            const float rn = (p.res_sumsq != nullptr) ? s_rn[base_pp[i]] : 1.f;
+            const float rn = e_hrss ? s_rn[base_pp[i]] : 1.f;
             const int cobase = co0 + wn * WN + 4 * lh;
-            const int sp = (p.epi == EPI_RESIDUAL && p.res) ? src_pixel(n, y, x, p.res_Hs, p.res_Ws, p.res_resample) : 0;
+            const int sp = (e_epi == EPI_RESIDUAL && e_hres) ? src_pixel(n, y, x, e_rHs, e_rWs, e_rrs) : 0;
             if (wide) {
                 // units of 8 couts (shared arithmetic: epi_unit8); the operand of unit u+1 is requested before unit u is computed
-                const size_t pix = ((size_t)n * p.H + y) * p.W + x;
-                T* orow = (T*)p.out + pix * p.out_cstride + co0 + wn * WN + 8 * lh;
-                const T* rrow = (const T*)p.res + (size_t)sp * p.res_cstride + co0 + wn * WN + 8 * lh;
-                const float* crow = p.cvec + (size_t)n * p.cvec_stride + cobase;
-                const float rs = p.res_scale * rn;
-                const bool has_res = p.epi == EPI_RESIDUAL && p.res != nullptr, want_ss = p.out_sumsq != nullptr, want_o2 = p.out2 != nullptr;
-                const SiluK k_o2 = silu_k(p.out2_scale);
+                const size_t pix = ((size_t)n * k_H + y) * k_W + x;
+                T* orow = (T*)p.out + pix * e_ocs + co0 + wn * WN + 8 * lh;
+                const T* rrow = (const T*)p.res + (size_t)sp * e_rcs + co0 + wn * WN + 8 * lh;
+                const float* crow = p.cvec + (size_t)n * e_cvs + cobase;
+                const float rs = e_rsc * rn;
+                const bool has_res = e_epi == EPI_RESIDUAL && e_hres, want_ss = e_hoss, want_o2 = e_ho2;
+                const SiluK k_o2 = silu_k(e_o2s);
                 constexpr int NU = NT * 2;
                 f32x4 ca[2] = {}, cb[2] = {};
                 u32x4 rw[2] = {};
                 auto fetch = [&](int u, int s_) {
                     const int j = u >> 1, m = u & 1;
-                    const bool in = co0 + wn * WN + j * 32 < p.Cout;
+                    const bool in = co0 + wn * WN + j * 32 < e_Cout;
 #ifdef TD_ABL_EPI_NOLD  // tools/conv_bench.hip ablations of the epilogue: operand loads / arithmetic / stores removed one at a time
                     (void)in; ca[s_] = f32x4{1.f, 1.f, 1.f, 1.f}; cb[s_] = ca[s_]; rw[s_] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
 #else
-                    if (p.epi == EPI_EMB_SILU) { ca[s_] = *(const f32x4*)(crow + (in ? j * 32 + m * 16 : 0)); cb[s_] = *(const f32x4*)(crow + (in ? j * 32 + m * 16 : 0) + 8); }
+                    if (e_epi == EPI_EMB_SILU) { ca[s_] = *(const f32x4*)(crow + (in ? j * 32 + m * 16 : 0)); cb[s_] = *(const f32x4*)(crow + (in ? j * 32 + m * 16 : 0) + 8); }
                     else if (has_res) rw[s_] = *(const u32x4*)(rrow + (in ? j * 32 + m * 16 : 0));
 #endif
                 };
@@ -540,7 +549,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
                 for (int u = 0; u < NU; ++u) {
                     const int j = u >> 1, m = u & 1, s_ = u & 1;
                     if (u + 1 < NU) fetch(u + 1, s_ ^ 1);
-                    if (co0 + wn * WN + j * 32 >= p.Cout) continue;
+                    if (co0 + wn * WN + j * 32 >= e_Cout) continue;
                     const f32x4 va = {acc[i][j][8 * m + 0], acc[i][j][8 * m + 1], acc[i][j][8 * m + 2], acc[i][j][8 * m + 3]};
                     const f32x4 vb = {acc[i][j][8 * m + 4], acc[i][j][8 * m + 5], acc[i][j][8 * m + 6], acc[i][j][8 * m + 7]};
                     u32x4 o, o2;
@@ -548,7 +557,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
                     o = u32x4{__builtin_bit_cast(unsigned, va[0]) ^ rw[s_][0], __builtin_bit_cast(unsigned, va[1]) ^ __builtin_bit_cast(unsigned, ca[s_][0]), __builtin_bit_cast(unsigned, vb[0]), __builtin_bit_cast(unsigned, vb[1])};
                     o2 = u32x4{__builtin_bit_cast(unsigned, va[2]), __builtin_bit_cast(unsigned, va[3]), __builtin_bit_cast(unsigned, vb[2]), __builtin_bit_cast(unsigned, vb[3]) ^ __builtin_bit_cast(unsigned, cb[s_][0])};
 #else
-                    epi_unit8<T>(p.epi, has_res, p.clip, want_ss, want_o2, va, vb, ca[s_], cb[s_], rw[s_], rs, k_o2, o, o2, ssj[j]);
+                    epi_unit8<T>(e_epi, has_res, e_clip, want_ss, want_o2, va, vb, ca[s_], cb[s_], rw[s_], rs, k_o2, o, o2, ssj[j]);
 #endif
 #ifdef TD_ABL_EPI_NOST
                     if (o[0] == 0x12345678u && o2[1] == 0x9abcdef0u && (!want_o2 || o2[0] == 77u)) *(u32x4*)(orow + j * 32 + m * 16) = o;
@@ -575,12 +584,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
                 }
             }
         }
-        if (p.out_sumsq) {
+        if (e_hoss) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const float ss = ssj[j] + __shfl_xor(ssj[j], 32);
-                if (ok && lh == 0 && co0 + wn * WN + j * 32 < p.CoutPad) {
-                    const size_t pix = ((size_t)n * p.H + y) * p.W + x;
+                if (ok && lh == 0 && co0 + wn * WN + j * 32 < k_cpad) {
+                    const size_t pix = ((size_t)n * k_H + y) * k_W + x;
                     p.out_sumsq[(size_t)((co0 + wn * WN) / 32 + j) * M + pix] = ss;
                 }
             }

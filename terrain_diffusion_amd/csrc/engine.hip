@@ -740,7 +740,20 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                         if (fnt == 1 || fnt == 2) { nt = (int)fnt; ks = 1; }
                         op.flavor = 4; op.sb_mt = mt; op.sb_nt = nt; p.ksplit = ks < 1 ? 1 : ks;
                         p.tiles_x = (w + TWs - 1) / TWs; p.tiles_y = (h + th_of(mt) - 1) / th_of(mt); p.img_groups = N; p.n_ntiles = cw.cout_pad / (32 * nt);
-                        p.wpack_sb = cw.packed_sb->p; p.sb_n3 = cw.sb_n3; p.sb_order = (int)u->eng->option("sb_order", 0);
+                        p.wpack_sb = cw.packed_sb->p; p.sb_n3 = cw.sb_n3;
+                        // workgroup order (speed only): the operand that is larger decides which siblings share an XCD's L2.  Weights (every layer
+                        // of a single tile: 0.2 - 21 MB against <= 4.7 MB of activations): the pixel tiles of a cout tile are adjacent, so an XCD
+                        // fetches few cout tiles' weights instead of all of them (batch 1: 1636 -> 1121 MB fetched per forward, tools/r04_order.sh);
+                        // activations (larger batches): the cout tiles of a pixel tile are adjacent and share the halo patch.  Option sb_order forces.
+                        {
+                            double wbytes = 0.0, abytes = 0.0;
+                            for (int i = 0; i < p.nseg; ++i) {
+                                wbytes += (double)(p.seg[i].C / chunk) * p.seg[i].taps * cw.cout_pad * 128.0;
+                                abytes += (double)N * p.seg[i].Hs * p.seg[i].Ws * p.seg[i].C * 2.0;
+                            }
+                            const int64_t fo = u->eng->option("sb_order", -1);
+                            p.sb_order = fo == 0 || fo == 1 ? (int)fo : (wbytes >= abytes ? 1 : 0);
+                        }
                     }
                 }
             }

@@ -126,7 +126,7 @@ def test_ragged_map_and_workgroup_order(td, orc):
             y = m(x, t, [c])
             fl = _flavours(eng, m, (x, t, [c]))
         finally:
-            eng.set_option("sb_order", 0)
+            eng.set_option("sb_order", -1)   # back to the planner's choice
         assert any(v.startswith("f4") for v in fl.values()), fl
         e = rel_rms(y.cpu().numpy(), ref.cpu().numpy())
         print(f"ragged 72x72, sb_order {order}: rel-RMS vs the per-tap flavour {e:.3e}")
