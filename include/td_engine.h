@@ -158,6 +158,16 @@ int td_sample_consistency_img(td_unet* u, int n, int H, int W, float t, float si
 int td_blend_windows(td_engine* e, float* canvas, int C, int Hc, int Wc, int size, int n_rows, const int32_t* row_starts_host,
                      int n_cols, const int32_t* col_starts_host, int n_tiles, const int32_t* wi_host, const int32_t* wj_host,
                      const float* tiles, int accumulate);
+
+/* Many equally sized regions of ONE lazily evaluated window tensor in one launch: what the reference's `InfiniteTensor.__getitem__` does
+ * slice by slice when a stage function is handed the argument slices of its windows (infinite_tensor call sites world_pipeline.py:982-992,
+ * 1146-1201, 1259-1270; annotated_infinite_panorama.py:153-226).  out: [n_regions][C+1][h][w] device fp32 = (sum_w out_w * win, sum_w win)
+ * over the windows listed for the region; desc_host: [n_regions][maxk][3] int32 = (slot into window_ptrs_host, row of the window's first
+ * pixel relative to the region, column likewise), slot < 0 ends a region's list, windows in ascending (row, col) order (the reference's
+ * summation order: results are bit-identical to td_blend_windows region by region); window_ptrs_host: device addresses of the raw window
+ * outputs [C][size][size]. */
+int td_gather_regions(td_engine* e, int C, int size, int n_regions, int h, int w, int maxk, const int32_t* desc_host, int n_windows,
+                      const uint64_t* window_ptrs_host, float* out);
 /* out[c] = canvas[c]/canvas[C]*scale, out: (C,Hc,Wc) */
 int td_blend_normalize(td_engine* e, const float* canvas, int C, int Hc, int Wc, float scale, float* out);
 /* linear_weight_window(size) (world_pipeline.py:117-124) -> out[size*size] */

@@ -55,6 +55,7 @@ _SIGS = {
     "td_sample_edm_img": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, _P, C.c_int, _P]),
     "td_sample_consistency_img": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, C.c_int, _P]),
     "td_blend_windows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int]),
+    "td_gather_regions": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
     "td_blend_normalize": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "td_linear_weight_window": (C.c_int, [_P, C.c_int, _P]),
     "td_attention": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P]),

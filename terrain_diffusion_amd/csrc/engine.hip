@@ -107,6 +107,8 @@ struct td_engine {
     std::map<std::string, std::pair<double, int64_t>> prof_ops;  // label -> (ms, launches)
     double prof_glds_ms = 0.0, prof_glds_flop = 0.0;             // the LDS-DMA conv kernel family alone
     int64_t prof_glds_launches = 0;
+    std::map<int, std::unique_ptr<struct DevBuf>> wwin;   // linear weight window per tile size, uploaded once (td_gather_regions)
+    std::unique_ptr<struct DevBuf> gather_stage;           // descriptor staging of td_gather_regions (grown on demand)
     int64_t option(const char* k, int64_t dflt) const { auto it = opt.find(k); return it == opt.end() ? dflt : it->second; }
 };
 
@@ -1642,6 +1644,40 @@ int td_blend_windows(td_engine* e, float* canvas, int C, int Hc, int Wc, int siz
     HIP_TRY(hipGetLastError());
     if (!cdev) HIP_TRY(hipMemcpyAsync(canvas, dcanvas, cbytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return TD_OK;
+}
+
+int td_gather_regions(td_engine* e, int C, int size, int n_regions, int h, int w, int maxk, const int32_t* desc_host, int n_windows,
+                      const uint64_t* window_ptrs_host, float* out) {
+    DevGuard dg_(e->device);
+    if (C + 1 > 8) return fail(TD_ERR_UNSUPPORTED, "C+1 must be <= 8");
+    if (n_regions <= 0) return TD_OK;
+    if (maxk < 1 || h < 1 || w < 1 || n_windows < 0 || !is_device_ptr(out)) return fail(TD_ERR_ARG, "td_gather_regions: bad shape / host output");
+    for (size_t i = 0; i < (size_t)n_regions * maxk; ++i)
+        if (desc_host[i * 3] >= n_windows) return fail(TD_ERR_ARG, "td_gather_regions: window slot out of range");
+    hipStream_t st = e->stream;
+    auto& ww = e->wwin[size];
+    if (!ww) {
+        std::vector<float> hw;
+        weight_window_host(size, hw);
+        ww.reset(new DevBuf());
+        HIP_TRY(ww->alloc(hw.size() * 4, false));
+        HIP_TRY(hipMemcpy(ww->p, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    }
+    const size_t dbytes = (size_t)n_regions * maxk * 3 * 4, pbytes = ((size_t)n_windows * 8 + 15) / 16 * 16, need = pbytes + dbytes;
+    if (!e->gather_stage || e->gather_stage->bytes < need) {
+        HIP_TRY(hipStreamSynchronize(st));   // a previous call's kernel may still read the old staging buffer
+        e->gather_stage.reset(new DevBuf());
+        HIP_TRY(e->gather_stage->alloc(std::max<size_t>(need * 2, 1 << 16), false));
+    }
+    unsigned char* stg = (unsigned char*)e->gather_stage->p;
+    // pageable sources: the runtime copies them to its own staging before returning, and the synchronous end of the call covers the rest
+    if (n_windows) HIP_TRY(hipMemcpyAsync(stg, window_ptrs_host, (size_t)n_windows * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(stg + pbytes, desc_host, dbytes, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(regions_gather_kernel, dim3((unsigned)(((size_t)h * w + 255) / 256), (unsigned)n_regions), dim3(256), 0, st, (const float* const*)stg,
+                       (const int*)(stg + pbytes), maxk, (const float*)ww->p, out, C, h, w, size);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));   // the descriptor staging is reused by the next call; window tensors may be released by the caller
     return TD_OK;
 }
 

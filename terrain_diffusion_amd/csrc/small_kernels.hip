@@ -386,11 +386,38 @@ __global__ void blend_gather_kernel(const float* __restrict__ x, const float* __
             if (slot < 0) continue;
             const int ly = y - row_start[ic], lx = xq - col_start[jc];
             const float w = wwin[ly * size + lx];
-            for (int c = 0; c < C; ++c) acc[c] += x[(((size_t)slot * C + c) * size + ly) * size + lx] * w;
+            for (int c = 0; c < C; ++c) acc[c] = __builtin_fmaf(x[(((size_t)slot * C + c) * size + ly) * size + lx], w, acc[c]);   // spelled out: regions_gather_kernel must round identically
             acc[C] += w;
         }
     }
     for (int c = 0; c <= C; ++c) canvas[(size_t)c * Hc * Wc + i] = acc[c];
+}
+
+// Many equally sized regions of ONE window tensor in one launch (round 4: the lazy graph assembles the argument slices of a whole batch of
+// windows at once -- td_blend_windows per slice cost six device allocations, six uploads and a stream synchronisation each, ~130 calls per
+// batch of 64 latent windows, and left the GPU idle 43 % of a cascade step).  Region r is (C+1, h, w); its candidate windows are listed in
+// desc[r][0 .. maxk) as (slot into `wins`, y of the window's first row relative to the region, x likewise), slot < 0 = end of list, in
+// ascending (row, col) window order: the same per-pixel summation order and arithmetic as blend_gather_kernel, so the bits are the same.
+__global__ void regions_gather_kernel(const float* const* __restrict__ wins, const int* __restrict__ desc, int maxk, const float* __restrict__ wwin,
+                                      float* __restrict__ out, int C, int h, int w, int size) {
+    const int r = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= h * w) return;
+    const int y = i / w, xq = i % w;
+    float acc[8];
+    for (int c = 0; c <= C; ++c) acc[c] = 0.f;
+    const int* d = desc + (size_t)r * maxk * 3;
+    for (int k = 0; k < maxk; ++k) {
+        const int slot = d[k * 3];
+        if (slot < 0) break;
+        const int ly = y - d[k * 3 + 1], lx = xq - d[k * 3 + 2];
+        if (ly < 0 || ly >= size || lx < 0 || lx >= size) continue;
+        const float wt = wwin[ly * size + lx];
+        const float* x = wins[slot];
+        for (int c = 0; c < C; ++c) acc[c] = __builtin_fmaf(x[((size_t)c * size + ly) * size + lx], wt, acc[c]);
+        acc[C] += wt;
+    }
+    float* o = out + (size_t)r * (C + 1) * h * w;
+    for (int c = 0; c <= C; ++c) o[(size_t)c * h * w + i] = acc[c];
 }
 
 // out[c] = canvas[c] / canvas[C] * scale   (normalise-on-read)

@@ -361,10 +361,18 @@ class DeviceWindowTensor(InfiniteTensor):
         self._prefetch_upstream(missing)
         plan = self._plan_batches(len(missing)) if (self.batch_size and self.batch_sizes) else None
         for ci, chunk in enumerate(self._chunks(missing) if self.batch_size else [missing] if missing else []):
-            arg_lists = [[a[tuple(slice(l, h) for l, h in aw.bounds(c))] for c in chunk] for a, aw in zip(self.args, self.args_windows)]
+            # the argument slices of the whole chunk: ONE gather launch per upstream device tensor (gather_many), per-window slicing otherwise
+            arg_lists = []
+            for a, aw in zip(self.args, self.args_windows):
+                bounds = [aw.bounds(c) for c in chunk]
+                if isinstance(a, DeviceWindowTensor) and all(b[0] == (0, a.channels + 1) for b in bounds):
+                    arg_lists.append(a.gather_many(bounds))
+                else:
+                    arg_lists.append([a[tuple(slice(l, h) for l, h in b)] for b in bounds])
             pad = (plan[ci] - len(chunk)) if plan else 0
             if pad > 0:   # padded plan: repeat the last window up to the allowed batch size (results of the repeats are dropped)
-                res = self.f(list(chunk) + [chunk[-1]] * pad, *[al + [al[-1]] * pad for al in arg_lists])[:len(chunk)]
+                rep = lambda al: torch.cat([al, al[-1:].expand(pad, *al.shape[1:])]) if torch.is_tensor(al) else al + [al[-1]] * pad
+                res = self.f(list(chunk) + [chunk[-1]] * pad, *[rep(al) for al in arg_lists])[:len(chunk)]
             else:
                 res = self.f(list(chunk), *arg_lists)
             assert res.is_cuda and tuple(res.shape) == (len(chunk), self.channels, self.tile, self.tile), (tuple(res.shape), res.device)
@@ -373,6 +381,32 @@ class DeviceWindowTensor(InfiniteTensor):
                 t = res[k].clone()   # own storage: the batch tensor can be freed while the window stays cached
                 self.tile_store.put((self.tensor_id, c), t)
                 out[c] = t
+        return out
+
+    def gather_many(self, bounds):
+        """bounds: [((0, C+1), (y0, y1), (x0, x1)), ...], all regions of one size -> device tensor (n, C+1, y1-y0, x1-x0): every region assembled
+        from the raw window outputs by ONE launch of the engine's region-gather kernel (td_gather_regions), same per-pixel window order and
+        arithmetic as the region-by-region path.  Missing windows (and their upstream) are computed first, in as few batches as allowed."""
+        import numpy as np
+        from ._lib import lib, check
+        from .engine import ptr
+        n = len(bounds)
+        h, w = bounds[0][1][1] - bounds[0][1][0], bounds[0][2][1] - bounds[0][2][0]
+        assert all(b[1][1] - b[1][0] == h and b[2][1] - b[2][0] == w for b in bounds), "gather_many: regions of one size only"
+        per = [sorted(self._windows_for([0, b[1][0], b[2][0]], [self.channels + 1, b[1][1], b[2][1]])) for b in bounds]
+        tiles = self._ensure(sorted({c for p_ in per for c in p_}))
+        order = {c: k for k, c in enumerate(tiles)}
+        maxk = max(1, max(len(p_) for p_ in per))
+        desc = np.full((n, maxk, 3), -1, dtype=np.int32)
+        oy, ox = self.output_window.offset[1], self.output_window.offset[2]
+        for r, (b, p_) in enumerate(zip(bounds, per)):
+            for k, c in enumerate(p_):
+                desc[r, k] = (order[c], c[1] * self.stride_hw + oy - b[1][0], c[2] * self.stride_hw + ox - b[2][0])
+        keep = list(tiles.values())   # the window tensors stay alive (and where they are) until the synchronous call returns
+        ptrs = np.asarray([t.data_ptr() for t in keep], dtype=np.uint64)
+        out = torch.empty((n, self.channels + 1, h, w), dtype=torch.float32, device=self.device)
+        import ctypes as _C
+        check(lib().td_gather_regions(self.engine._h, self.channels, self.tile, n, h, w, maxk, _C.c_void_p(desc.ctypes.data), len(keep), _C.c_void_p(ptrs.ctypes.data), ptr(out)))
         return out
 
     def __getitem__(self, idx):

@@ -23,6 +23,12 @@ from . import noise as _noise
 from .sampling import _linear_weight_window
 
 
+def _stacked(x):
+    """argument slices of a batch of windows: the device-resident graph hands them over as ONE (n, ...) tensor (DeviceWindowTensor.gather_many),
+    the host-resident graph as a list of per-window tensors"""
+    return x.to(torch.float32) if torch.is_tensor(x) else torch.stack([torch.as_tensor(p, dtype=torch.float32) for p in x])
+
+
 LATENT_COND_MEAN = (14.99, 11.65, 15.87, 619.26, 833.12, 69.40, 0.66)     # world_pipeline.py:1137-1138
 LATENT_COND_STD = (21.72, 21.78, 10.40, 452.29, 738.09, 34.59, 0.47)
 
@@ -41,7 +47,7 @@ def build_latent_stage(model, sigma_data=0.5, sigma_max=80.0, *, seed, cond_fn=N
     (world_pipeline.py:1149-1172).  onestep_latent stops after the first phase.
     device_resident=True: windows stay in HBM (DeviceWindowTensor / DeviceTileStore), regions are assembled by the engine's blend kernel and
     slices are device tensors; False: host tensors and a host tile store exactly as the reference keeps them (world_pipeline.py:1129)."""
-    from .sampling import process_latent_conditioning
+    from .sampling import process_latent_conditioning_windows
     if (cond_fn is None) == (coarse is None):
         raise ValueError("give exactly one of cond_fn= or coarse=")
     stride = tile // 2
@@ -57,12 +63,10 @@ def build_latent_stage(model, sigma_data=0.5, sigma_max=80.0, *, seed, cond_fn=N
     def conditioning(ctxs, conds):
         if coarse is None:
             return torch.as_tensor(cond_fn(ctxs), dtype=torch.float32)
-        rows = []
-        for ctx, c in zip(ctxs, conds):
-            c = torch.as_tensor(c, dtype=torch.float32)
-            cimg = torch.cat([c[:-1] / c[-1:], torch.ones(1, 4, 4, device=c.device)], dim=0)[None]    # world_pipeline.py:1080-1083
-            rows.append(process_latent_conditioning(cimg, hist, cond_means, cond_stds, 0.0, seed=seed, seed_offset=ctx[1] * 65536 + ctx[2]))
-        return torch.cat(rows, dim=0)
+        # all windows of the batch at once (round 4; the per-window loop cost ~30 tiny launches and one host synchronisation per window)
+        c = _stacked(conds)                                                                           # (n, 7, 4, 4) packed coarse slices
+        cimg = torch.cat([c[:, :-1] / c[:, -1:], torch.ones(c.shape[0], 1, 4, 4, device=c.device)], dim=1)   # world_pipeline.py:1080-1083
+        return process_latent_conditioning_windows(cimg, hist, cond_means, cond_stds, 0.0)
 
     def infer_raw(phase, t, ctxs, prevs, conds):
         """one trig-flow phase on a batch of windows -> (n, channels, tile, tile) on the device, divided by sigma_data (world_pipeline.py:1129)"""
@@ -71,7 +75,8 @@ def build_latent_stage(model, sigma_data=0.5, sigma_max=80.0, *, seed, cond_fn=N
         z = _noise.gaussian_noise_patches(seed + 5819 + phase, origins, tile, tile, channels=channels, tile_h=tile, tile_w=tile, device=dev)
         sample = None
         if prevs is not None:  # (C+1, tile, tile) un-normalised sums -> sample * sigma_data (world_pipeline.py:1078)
-            sample = torch.stack([(torch.as_tensor(p)[:-1] / torch.as_tensor(p)[-1:]) * sigma_data for p in prevs]).to(dev, dtype=torch.float32).contiguous()
+            pv = _stacked(prevs).to(dev)
+            sample = ((pv[:, :-1] / pv[:, -1:]) * sigma_data).contiguous()
         cond = conditioning(ctxs, conds).to(dev).contiguous()
         out = torch.empty_like(z)
         check(lib().td_sample_consistency(model._h, n, tile, tile, float(t), float(sigma_data), ptr(sample), ptr(z), ptr(cond), ptr(out)))
@@ -203,7 +208,8 @@ def build_decoder_stage(model, latents, *, seed, sigma_data=0.5, sigma_max=80.0,
     def f_raw(ctxs, lats):
         n = len(ctxs)
         origins = [(c[1] * S, c[2] * S) for c in ctxs]
-        lat = torch.stack([(torch.as_tensor(p)[:-1] / torch.as_tensor(p)[-1:])[:4] for p in lats]).to(dev, dtype=torch.float32)   # :1223
+        lv = _stacked(lats).to(dev)
+        lat = (lv[:, :-1] / lv[:, -1:])[:, :4]                                                                                     # :1223
         up = lat.repeat_interleave(T // lat.shape[-2], dim=-2).repeat_interleave(T // lat.shape[-1], dim=-1).contiguous()         # nearest, :1224
         sample = None
         for i, t in enumerate(t_list):

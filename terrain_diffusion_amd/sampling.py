@@ -85,6 +85,27 @@ def process_latent_conditioning(cond_img, histogram_raw, cond_means, cond_stds, 
     return torch.cat([p * (Cc / math.sqrt(p.shape[1]) * (1.0 / n)) for p in parts], dim=1).float()
 
 
+def process_latent_conditioning_windows(cond_imgs, histogram_raw, cond_means, cond_stds, noise_level=0.0):
+    """process_latent_conditioning applied to n windows ONE AT A TIME, as the reference's latent stage calls it (world_pipeline.py:1080-1088: a
+    (1,7,4,4) image per window), evaluated for all windows at once: (n,7,4,4) -> (n,58) with a dozen tensor ops instead of ~30 per window.
+    With a batch of one the reference's batch-dimension NaN fill (`cond_img[0:1].nan_to_num(cond_means[0])`) covers every channel of the
+    window, so no NaN reaches the climate means and the per-window RNG fill (seed + 9999 + seed_offset) is never drawn: the vectorised form
+    needs neither a seed nor a device-to-host synchronisation (the per-window form reads `nan_mask.sum()` back for every window)."""
+    x = torch.as_tensor(cond_imgs, dtype=torch.float32)
+    dev = x.device
+    cond_means = torch.as_tensor(cond_means, dtype=torch.float32)
+    cond_stds = torch.as_tensor(cond_stds, dtype=torch.float32)
+    x = ((x - cond_means.view(1, -1, 1, 1).to(dev)) / cond_stds.view(1, -1, 1, 1).to(dev)).nan_to_num(float(cond_means[0]))
+    clim = x[:, 2:6, 1:3, 1:3].mean(dim=(2, 3))
+    B = x.shape[0]
+    nl = ((torch.as_tensor(noise_level, dtype=torch.float32) - 0.5) * np.sqrt(12)).to(dev)
+    hist = torch.as_tensor(histogram_raw, dtype=torch.float32).to(dev)
+    parts = [x[:, 0:1].flatten(1), x[:, 1:2].flatten(1), clim.flatten(1), x[:, 6:7].flatten(1), hist.view(-1, hist.shape[-1]).expand(B, -1), nl.view(-1, 1).expand(B, 1)]
+    n = len(parts)
+    Cc = math.sqrt(sum(p.shape[1] for p in parts) / (n * (1.0 / n) ** 2))
+    return torch.cat([p * (Cc / math.sqrt(p.shape[1]) * (1.0 / n)) for p in parts], dim=1).float()
+
+
 def _tile_conditioning(cond_inputs, tiles, histogram_raw, cond_means, cond_stds, noise_level):
     if cond_inputs.ndim == 4:
         return torch.cat([_process_cond_img(cond_inputs[..., ic:ic + 4, jc:jc + 4], histogram_raw, cond_means, cond_stds, noise_level)

@@ -66,3 +66,21 @@ def test_laplacian_round_trip_and_denoise_properties():
     assert r2 is res and low2.shape == low.shape
     c_res, c_low = compose.laplacian_encode(torch.full((64, 64), 3.5), 8, 5)
     assert c_res.abs().max() < 1e-5 and torch.allclose(c_low, torch.full((8, 8), 3.5), atol=1e-5)
+
+
+def test_latent_conditioning_of_a_batch_of_windows_equals_the_per_window_loop():
+    """round 4: the latent stage evaluates the conditioning of all windows of a batch at once (process_latent_conditioning_windows).  The
+    reference calls _process_latent_conditioning once per window with a batch of ONE (world_pipeline.py:1080-1088), where its batch-dimension
+    NaN fill covers the whole window; the vectorised form must reproduce that loop bit for bit, NaNs and infinities included."""
+    import numpy as np
+    import torch
+    from terrain_diffusion_amd.sampling import process_latent_conditioning, process_latent_conditioning_windows
+    from terrain_diffusion_amd.pipeline import LATENT_COND_MEAN, LATENT_COND_STD
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(9, 7, 4, 4, generator=g) * torch.tensor(LATENT_COND_STD).view(1, -1, 1, 1) + torch.tensor(LATENT_COND_MEAN).view(1, -1, 1, 1)
+    x[1, 0, 2, 3] = float("nan"); x[2, 3, 1, 1] = float("nan"); x[4, 2:6] = float("nan"); x[5, 1, 0, 0] = float("inf"); x[7] = float("nan")
+    hist = torch.randn(1, 5, generator=g)
+    loop = torch.cat([process_latent_conditioning(x[i:i + 1].clone(), hist, LATENT_COND_MEAN, LATENT_COND_STD, 0.0, seed=77, seed_offset=i * 65536 + 3) for i in range(9)])
+    vec = process_latent_conditioning_windows(x.clone(), hist, LATENT_COND_MEAN, LATENT_COND_STD, 0.0)
+    assert vec.shape == loop.shape == (9, 58)
+    assert torch.equal(vec, loop), float((vec - loop).abs().max())
