@@ -13,6 +13,8 @@ F.interpolate / conv2d in tests (oracle/compose.py), which is what torchvision c
 import ctypes as C
 import math
 
+import functools
+
 import numpy as np
 import torch
 
@@ -24,6 +26,7 @@ ELEV_SIGMA = 5                                     # world_pipeline.py:1284
 
 
 # ------------------------------------------------------------------------------------------------ tap tables (host, tiny)
+@functools.lru_cache(maxsize=256)   # pure functions of the sizes: a request stream asks for the same few tables over and over (23 ms of Python per cascade step)
 def bilinear_taps(n_in, n_out):
     """torch upsample_bilinear2d, align_corners=False: two taps per output index, fp32 source coordinates clamped at 0."""
     scale = np.float32(n_in) / np.float32(n_out)
@@ -36,6 +39,7 @@ def bilinear_taps(n_in, n_out):
     return np.stack([i0, i1], 1).astype(np.int32), np.stack([l0, l1], 1).astype(np.float32)
 
 
+@functools.lru_cache(maxsize=256)   # pure functions of the sizes: a request stream asks for the same few tables over and over (23 ms of Python per cascade step)
 def bilinear_aa_taps(n_in, n_out):
     """torch _upsample_bilinear2d_aa (what TF.resize(..., antialias=True) runs): triangle filter of half-width max(scale, 1)."""
     scale = n_in / n_out
@@ -59,6 +63,7 @@ def bilinear_aa_taps(n_in, n_out):
     return idx, wts
 
 
+@functools.lru_cache(maxsize=256)   # pure functions of the sizes: a request stream asks for the same few tables over and over (23 ms of Python per cascade step)
 def gaussian_taps(n, sigma):
     """torchvision gaussian_blur: kernel_size = int(sigma*2)//2*2 + 1 samples of exp(-x^2 / 2 sigma^2) on linspace(-h, h), normalised, reflect padding."""
     k = int(sigma * 2) // 2 * 2 + 1

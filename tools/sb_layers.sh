@@ -1,7 +1,7 @@
 #!/bin/bash
 # Battery of base-model layer shapes for tools/sb_bench.out (correctness vs the per-tap flavour, hot / cold timing, conv_glds split-K beside it).
 # usage: tools/sb_layers.sh [order]     args of sb_bench: N H W Cin Cout mt nt Cin1x1 epi xform order resample glds_ks out2
-B=tools/sb_bench.out; O=${1:-0}
+B=tools/sb_bench.out; O=${1:-0}   # sb_bench.out: hipcc ... -DSB_WITH_GLDS (conv_glds split-K beside every line)
 run() { echo "--- $*"; timeout 120 $B "$@" || echo "FAILED($?) $*"; }
 echo "== level A 64x64"
 run 1 64 64 64 192 2 2 0 0 0 $O 0 1
