@@ -671,6 +671,12 @@ static hipError_t launch_conv_glds_t(const ConvParams& p, bool narrow, int bn, i
         return variant == 1 ? launch_glds_cfg<T, 8, 16, 1, 64, 4, 1>(p, st) : launch_glds_cfg<T, 16, 16, 1, 64, 8, 1>(p, st);
     }
     if (variant == 2) return hipErrorInvalidValue;
+#ifdef TD_BN192   // tools/conv_bench.hip only: all 192 couts of the 64x64 level in one workgroup (profiles/r04_conv_bn192_tile.txt)
+    if (bn == 192) {
+        if (narrow) return hipErrorInvalidValue;
+        return variant == 1 ? launch_glds_cfg<T, 8, 16, 1, 192, 2, 2>(p, st) : launch_glds_cfg<T, 16, 16, 1, 192, 4, 2>(p, st);
+    }
+#endif
     if (variant == 1) {
         if (!narrow) return bn == 128 ? launch_glds_cfg<T, 8, 16, 1, 128, 2, 2>(p, st) : launch_glds_cfg<T, 8, 16, 1, 96, 4, 1>(p, st);
         return bn == 128 ? launch_glds_cfg<T, 8, 8, 2, 128, 2, 2>(p, st) : launch_glds_cfg<T, 8, 8, 2, 96, 4, 1>(p, st);
@@ -681,6 +687,9 @@ static hipError_t launch_conv_glds_t(const ConvParams& p, bool narrow, int bn, i
 
 // dtype: 1 bf16, 2 fp16 (this flavour has no fp32 form)
 hipError_t launch_conv_glds(const ConvParams& p, int dtype, bool narrow, int bn, int variant, hipStream_t st) {
+#ifdef TD_BN192
+    if (bn == 192) return launch_conv_glds_t<__bf16>(p, narrow, bn, variant, st);
+#endif
     if (bn != 64 && bn != 96 && bn != 128) return hipErrorInvalidValue;
     return dtype == 2 ? launch_conv_glds_t<_Float16>(p, narrow, bn, variant, st) : launch_conv_glds_t<__bf16>(p, narrow, bn, variant, st);
 }

@@ -100,6 +100,17 @@ int main(int argc, char** argv) {
         size_t bad = 0, nz = 0; for (size_t i = 0; i < o0.size(); ++i) { bad += o0[i] != o1[i]; nz += (o1[i] & 0x7fff) != 0; }
         printf("  check dma1x1 1 vs 0: %zu / %zu outputs differ, nonzero outputs %zu%s\n", bad, o0.size(), nz, ksplit > 1 ? "  (split-K: `out` is written by the reduce launch)" : "");
     }
+    if (getenv("TD_CMP_BN") && (flavor == 2 || flavor == 3)) {   // same K order, same MFMA: another cout tile width must give the same bits
+        const int bn0 = atoi(getenv("TD_CMP_BN"));
+        std::vector<uint16_t> o0(M * Cout), o1(M * Cout);
+        CK(hipMemset(out, 0, M * Cout * 2)); CK(L(p)); CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(o1.data(), out, o1.size() * 2, hipMemcpyDeviceToHost));
+        ConvParams q = p; q.n_ntiles = Cout / bn0; q.tiles_y = (H + 7) / 8;
+        CK(hipMemset(out, 0, M * Cout * 2)); CK(launch_conv_glds(q, 1, narrow, bn0, 1, st)); CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(o0.data(), out, o0.size() * 2, hipMemcpyDeviceToHost));
+        size_t bad = 0, nz = 0; for (size_t i = 0; i < o0.size(); ++i) { bad += o0[i] != o1[i]; nz += (o1[i] & 0x7fff) != 0; }
+        printf("  check vs bn%d small: %zu / %zu outputs differ, nonzero outputs %zu\n", bn0, bad, o0.size(), nz);
+    }
     if (flavor == 5) {  // bit-exactness of the persistent ping-pong flavour against the LDS-DMA flavour (same K order, same MFMA)
         std::vector<uint16_t> o5(M * Cout), o2(M * Cout);
         CK(hipMemset(out, 0, M * Cout * 2));
