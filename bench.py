@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"])
     ap.add_argument("--edm-steps", type=int, default=20)
     ap.add_argument("--region", type=int, default=0, help="cascade workload: side of the decoded region per step in pixels (default 3072 at N=1, 6144 at N>1)")
+    ap.add_argument("--cascade-sync", type=int, default=0, help="cascade workload: 1 = every engine call synchronous (complete on return) instead of enqueue-only on one stream")
     ap.add_argument("--cache-mib", type=int, default=100, help="cascade workload: window-cache cap in MiB (default = the reference's cache_limit)")
     ap.add_argument("--engine-opts", default="", help="engine options for A/B runs, e.g. dual_stream=0,pp=1 (recorded in config.engine_opts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

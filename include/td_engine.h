@@ -69,10 +69,14 @@ void* td_engine_stream(td_engine* e);
 /* Caller-supplied stream: every later call enqueues on `hip_stream` (a hipStream_t created by the caller -- e.g. the
  * torch.cuda.Stream that also carries the caller's own kernels and its RCCL transfers; NOT the legacy NULL stream, which cannot be captured
  * into the engine's hipGraphs); NULL restores the engine's own stream.  The old stream is drained first.  By default every call still returns
- * with its results complete; with td_engine_set_option(e, "async", 1) a call whose buffers are all device pointers (td_sample_edm*,
- * td_sample_consistency*, td_blend_normalize) only ENQUEUES its work, ordered with whatever else the caller puts on that stream, and
- * td_engine_synchronize() (or the caller's own stream synchronisation followed by it) releases the calls' staging buffers.  The reference
- * gets the same ordering from torch's current-stream semantics (world_pipeline.py:941-949 runs model and scheduler ops on one stream). */
+ * with its results complete; with td_engine_set_option(e, "async", 1) a call whose DATA buffers are all device pointers (td_sample_edm*,
+ * td_sample_consistency*, td_noise_patches, td_gather_regions, td_blend_windows, td_blend_normalize, td_resample2d, td_residual_plus,
+ * td_elev_finish, td_climate_finish, td_ddim_cfg_step) only ENQUEUES its work, ordered with whatever else the caller puts on that stream.
+ * The small host arrays such calls take (origins, descriptors, tap tables, timesteps) are copied into a pinned ring inside the call, so the
+ * caller may reuse them on return; device buffers must stay valid in STREAM order (a torch tensor released on that stream is).  Per-call
+ * device scratch comes from a stream-ordered pool, never from hipMalloc / hipFree in the steady state.  td_engine_synchronize() drains.
+ * The reference gets the same ordering from torch's current-stream semantics (world_pipeline.py:941-949 runs model and scheduler ops on
+ * one stream); round 4's cascade runs this way end to end (terrain_diffusion_amd/cascade_bench.py). */
 int td_engine_set_stream(td_engine* e, void* hip_stream);
 /* knobs: "graph"=0/1, "splitk"=0/1, "batch_invariant"=0/1, "solver_order"=1/2 (EDMDPMSolverMultistepScheduler.config.solver_order),
  * "glds_variant"=-1/0/1 and "glds_bn"=0/96/128 (force the conv tile shape: test hook), "plan_cache_mb", "plan_cache_max", "profile"=0/1,

@@ -54,16 +54,23 @@ def run_cascade(args, eng, dev, rank, world):
     def sync():
         eng.synchronize()
         torch.cuda.synchronize()
-    for i in range(args.warmup):
-        one_step(-(i + 1))
-    sync()
-    for t in (world_p.coarse, world_p.latents, world_p.residual):
-        t.windows_computed = 0
-    ev0 = world_p.tile_store.evictions
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = one_step(i)
-    sync()
+    # The requests run with the engine on torch's current stream and in enqueue-only mode (Engine.on_stream = td_engine_set_stream + option "async"):
+    # sampler launches, region gathers, composition and the torch ops between them are ordered by ONE stream, and the host -- lazy-graph
+    # bookkeeping, descriptor tables, Python -- runs ahead of the GPU instead of waiting for every call (--cascade-sync 1: the synchronous C-ABI
+    # default, results complete on return of every call, as in rounds 2-3)
+    import contextlib
+    enqueue_only = not int(getattr(args, "cascade_sync", 0))
+    with (eng.on_stream(torch.cuda.Stream(device=dev)) if enqueue_only else contextlib.nullcontext()):
+        for i in range(args.warmup):
+            one_step(-(i + 1))
+        sync()
+        for t in (world_p.coarse, world_p.latents, world_p.residual):
+            t.windows_computed = 0
+        ev0 = world_p.tile_store.evictions
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = one_step(i)
+        sync()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -123,7 +130,8 @@ def run_cascade(args, eng, dev, rank, world):
                    "decoded_mp_per_step": mp, "parallelism": (f"{world} ranks, request-replica mode: one world, requests dealt in Z-curve order, no data-path collective" if world > 1 else "1 rank"), "windows_per_step": {k: round(t.windows_computed / args.steps, 1) for k, t in
                                                                    (("coarse", world_p.coarse), ("latent_final_phase", world_p.latents), ("decoder", world_p.residual))},
                    "cache_evictions_per_step": round((world_p.tile_store.evictions - ev0) / args.steps, 1),
-                   "requests_per_step": split.get("requests_per_step"), "requests_per_rank": per_rank},
+                   "requests_per_step": split.get("requests_per_step"), "requests_per_rank": per_rank,
+                   "engine_calls": "enqueue-only on one stream shared with torch (Engine.on_stream)" if enqueue_only else "synchronous (complete on return)"},
         "batch_sweep": {"what": "base U-Net forward (193.654 GFLOP per tile) at the latent stage's batch sizes, eager launches, wall ms per forward; "
                                 "the full 1 ... 64 sweep with HBM bytes is profiles/r04_batch_sweep.txt", "by_batch": sweep},
         "roofline": {"bound": "mfma", "kernel": "td::conv_glds_kernel (all stages)", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "achieved": round(tflops, 2),

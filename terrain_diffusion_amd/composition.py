@@ -171,7 +171,7 @@ def local_baseline_temperature(T, e, win=3, beta_clip=(-0.012, 0.0), fallback_be
     mu_T, mu_e, mu_e2, mu_eT = wavg(T), wavg(e), wavg(e * e), wavg(e * T)
     var_e = mu_e2 - mu_e ** 2
     beta = (mu_eT - mu_e * mu_T) / (var_e + eps)
-    beta = torch.where((var_e < 1.0) | (sum_w < fallback_threshold), torch.tensor(fallback_beta, device=beta.device), beta)
+    beta = torch.where((var_e < 1.0) | (sum_w < fallback_threshold), float(fallback_beta), beta)   # scalar overload: no host-to-device copy (and no sync)
     beta = torch.clamp(beta, beta_clip[0], beta_clip[1])
     pad = (win - 1) // 2
     T_sea = T[:, :, pad:-pad, pad:-pad] - beta * e[:, :, pad:-pad, pad:-pad]

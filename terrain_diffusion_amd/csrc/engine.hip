@@ -65,15 +65,46 @@ struct DevGuard {
     DevGuard& operator=(const DevGuard&) = delete;
 };
 
+// Per-call device scratch (I/O staging, descriptor tables, intermediate planes).  hipMalloc / hipFree cost tens of microseconds and hipFree
+// waits for the device, so scratch is recycled: a buffer handed back at the end of a call may be given to the next call at once, because all of
+// an engine's work is enqueued on ONE stream and the stream orders the two uses (td_engine_set_stream drains the stream before it changes).
+struct ScratchPool {
+    std::vector<std::pair<void*, size_t>> idle;
+    size_t idle_bytes = 0;
+    ~ScratchPool() { for (auto& b : idle) (void)hipFree(b.first); }
+    hipError_t take(size_t n, void** p, size_t* got) {
+        int best = -1;
+        for (int i = 0; i < (int)idle.size(); ++i)
+            if (idle[i].second >= n && idle[i].second <= 4 * n + 4096 && (best < 0 || idle[i].second < idle[best].second)) best = i;
+        if (best >= 0) { *p = idle[best].first; *got = idle[best].second; idle_bytes -= *got; idle[best] = idle.back(); idle.pop_back(); return hipSuccess; }
+        *got = (n + 4095) / 4096 * 4096;
+        return hipMalloc(p, *got);
+    }
+    void give(void* p, size_t n) {
+        idle.emplace_back(p, n); idle_bytes += n;
+        while (idle_bytes > ((size_t)1 << 30) || idle.size() > 64) {   // bounded: drop the oldest (hipFree waits for the device; rare)
+            (void)hipFree(idle.front().first); idle_bytes -= idle.front().second; idle.erase(idle.begin());
+        }
+    }
+};
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    ScratchPool* pool = nullptr;   // set: p came from the pool and goes back to it
     DevBuf() {}
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    void release() { if (p) { if (pool) pool->give(p, bytes); else (void)hipFree(p); p = nullptr; pool = nullptr; } }
+    ~DevBuf() { release(); }
+    hipError_t scratch(ScratchPool& sp, size_t n) {   // uninitialised per-call scratch
+        release();
+        hipError_t e = sp.take(n ? n : 16, &p, &bytes);
+        if (e == hipSuccess) pool = &sp; else p = nullptr;
+        return e;
+    }
     hipError_t alloc(size_t n, bool zero = true) {
-        if (p) { (void)hipFree(p); p = nullptr; }
+        release();
         bytes = n ? n : 16;
         hipError_t e = hipMalloc(&p, bytes);
         // hipMemset on device memory is asynchronous and runs on the NULL stream, which the engine's non-blocking stream does not wait
@@ -90,7 +121,43 @@ static bool is_device_ptr(const void* p) {
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+// Pinned host staging for the small uploads (timesteps, descriptor tables, tap tables) of calls that only enqueue (option "async"): the source
+// of a hipMemcpyAsync has to stay valid until the copy has run, and the caller's arrays do not.  Two halves; leaving a half records an event
+// behind everything enqueued from it, entering a half waits for its event (long past, in practice).
+struct PinnedRing {
+    static constexpr size_t HALF = (size_t)2 << 20;
+    unsigned char* base = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool pending[2] = {false, false};
+    int cur = 0;
+    size_t used = 0;
+    ~PinnedRing() { if (base) (void)hipHostFree(base); for (auto e : ev) if (e) (void)hipEventDestroy(e); }
+    // copies `bytes` from src into the ring; nullptr when it cannot (too large / allocation failure): the caller then ends the call synchronously
+    const void* stage(const void* src, size_t bytes, hipStream_t st) {
+        const size_t need = (bytes + 63) / 64 * 64;
+        if (need > HALF) return nullptr;
+        if (!base) {
+            if (hipHostMalloc((void**)&base, 2 * HALF, hipHostMallocDefault) != hipSuccess) { base = nullptr; (void)hipGetLastError(); return nullptr; }
+            for (auto& e : ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+        if (used + need > HALF) {
+            if (hipEventRecord(ev[cur], st) != hipSuccess) return nullptr;
+            pending[cur] = true;
+            cur ^= 1; used = 0;
+            if (pending[cur]) { if (hipEventSynchronize(ev[cur]) != hipSuccess) return nullptr; pending[cur] = false; }
+        }
+        unsigned char* d = base + (size_t)cur * HALF + used;
+        used += need;
+        memcpy(d, src, bytes);
+        return d;
+    }
+    void reset() { pending[0] = pending[1] = false; used = 0; }   // after a stream synchronise: nothing is in flight
+};
+
 struct td_engine {
+    ScratchPool scratch;       // first member: destroyed last, after every buffer that came from it
+    PinnedRing ring;
+    bool call_host_src = false;   // this call copied from a caller-owned host array that could not be staged: it must end synchronously
     int device = 0;
     int n_cus = 256;
     void* zeros = nullptr;     // 4 KiB of zeros: halo source of the LDS-DMA patch staging (conv_pp.hip)
@@ -108,17 +175,27 @@ struct td_engine {
     double prof_glds_ms = 0.0, prof_glds_flop = 0.0;             // the LDS-DMA conv kernel family alone
     int64_t prof_glds_launches = 0;
     std::map<int, std::unique_ptr<struct DevBuf>> wwin;   // linear weight window per tile size, uploaded once (td_gather_regions)
-    std::unique_ptr<struct DevBuf> gather_stage;           // descriptor staging of td_gather_regions (grown on demand)
     int64_t option(const char* k, int64_t dflt) const { auto it = opt.find(k); return it == opt.end() ? dflt : it->second; }
 };
+
+// host array -> device memory on the engine's stream.  Option "async": through the pinned ring, so that the call may return before the copy has run
+static int upload(td_engine* e, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return TD_OK;
+    if (e->option("async", 0) != 0) {
+        if (const void* pinned = e->ring.stage(src, bytes, e->stream)) { HIP_TRY(hipMemcpyAsync(dst, pinned, bytes, hipMemcpyHostToDevice, e->stream)); return TD_OK; }
+        e->call_host_src = true;
+    }
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream));
+    return TD_OK;
+}
 
 // Stages a possibly-host input into device memory (returns device pointer, owning buffers appended to `hold`).
 static int to_device(td_engine* e, const void* src, size_t bytes, std::vector<Buf>& hold, const void** out) {
     if (!src) { *out = nullptr; return TD_OK; }
     if (is_device_ptr(src)) { *out = src; return TD_OK; }
     Buf b(new DevBuf());
-    HIP_TRY(b->alloc(bytes, false));
-    HIP_TRY(hipMemcpyAsync(b->p, src, bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(b->scratch(e->scratch, bytes));
+    { int rc_ = upload(e, b->p, src, bytes); if (rc_) return rc_; }
     *out = b->p;
     hold.push_back(std::move(b));
     return TD_OK;
@@ -128,7 +205,7 @@ static int out_device(td_engine* e, void* dst, size_t bytes, std::vector<Buf>& h
     st->host = nullptr; st->bytes = bytes;
     if (is_device_ptr(dst)) { st->dev = dst; return TD_OK; }
     Buf b(new DevBuf());
-    HIP_TRY(b->alloc(bytes, false));
+    HIP_TRY(b->scratch(e->scratch, bytes));
     st->dev = b->p; st->host = dst;
     hold.push_back(std::move(b));
     return TD_OK;
@@ -145,13 +222,18 @@ static int out_finish(td_engine* e, const OutStage& st) {
 // pointers involved, the work stays enqueued on e->stream -- typically the caller's own stream (td_engine_set_stream), so that it is ordered
 // with the caller's other GPU work without a host synchronisation -- and the call's staging buffers are parked until td_engine_synchronize.
 static int end_call(td_engine* e, std::vector<Buf>& hold, bool all_device) {
-    if (all_device && e->option("async", 0) != 0) {
-        if (e->deferred.size() > 256) { HIP_TRY(hipStreamSynchronize(e->stream)); e->deferred.clear(); }
-        for (auto& b : hold) e->deferred.push_back(std::move(b));
+    const bool host_src = e->call_host_src;
+    e->call_host_src = false;
+    if (all_device && !host_src && e->option("async", 0) != 0) {
+        // pooled scratch goes straight back to the pool (the stream orders its next use behind this call's work); buffers that would be
+        // hipFree'd -- which waits for the device -- are parked until the next synchronise
+        if (e->deferred.size() > 256) { HIP_TRY(hipStreamSynchronize(e->stream)); e->deferred.clear(); e->ring.reset(); }
+        for (auto& b : hold) if (b && !b->pool) e->deferred.push_back(std::move(b));
         hold.clear();
         return TD_OK;
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
+    e->ring.reset();
     return TD_OK;
 }
 
@@ -958,10 +1040,9 @@ static int compute_cvecs(td_unet* u, Plan& pl, const std::vector<float>& t_steps
         HIP_TRY(pl.tsteps->alloc(std::max<size_t>(64, t_steps.size()) * 4));
         pl.cvec_rows = rows;
     }
-    HIP_TRY(hipMemcpyAsync(pl.tsteps->p, t_steps.data(), t_steps.size() * 4, hipMemcpyHostToDevice, st));
-    // `t_steps` lives on the caller's stack: with option "async" the call may return before the stream gets here, so the (80-byte) upload is
-    // waited for now rather than relying on the runtime staging pageable sources synchronously
-    if (u->eng->option("async", 0) != 0) HIP_TRY(hipStreamSynchronize(st));
+    // `t_steps` lives on the caller's stack: with option "async" the call may return before the stream gets here, so the (80-byte) upload goes
+    // through the engine's pinned ring
+    { int rc_ = upload(u->eng, pl.tsteps->p, t_steps.data(), t_steps.size() * 4); if (rc_) return rc_; }
     const int half = u->noise_dims / 2;
     hipLaunchKernelGGL(emb_kernel, dim3(rows, (u->emb_ch + 63) / 64), dim3(256), (size_t)(2 * half + u->embd.feat_total) * 4, st, (const float*)pl.tsteps->p, d_cond, pl.N,
                        (const float*)u->d_freqs->p, half, (const float*)u->d_wnoise->p, (const float*)u->d_wcond->p, (const float*)u->d_fourier->p,
@@ -1087,13 +1168,14 @@ void td_engine_destroy(td_engine* e) {
     delete e;
 }
 int td_engine_synchronize(td_engine* e) {
-    DevGuard dg_(e->device); HIP_TRY(hipStreamSynchronize(e->stream)); e->deferred.clear(); return TD_OK; }
+    DevGuard dg_(e->device); HIP_TRY(hipStreamSynchronize(e->stream)); e->deferred.clear(); e->ring.reset(); return TD_OK; }
 void* td_engine_stream(td_engine* e) { return (void*)e->stream; }
 int td_engine_set_stream(td_engine* e, void* hip_stream) {
     if (!e) return fail(TD_ERR_ARG, "null engine");
     DevGuard dg_(e->device);
     HIP_TRY(hipStreamSynchronize(e->stream));   // nothing of the old stream may be pending when the order of work changes hands
     e->deferred.clear();
+    e->ring.reset();
     e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
     return TD_OK;
 }
@@ -1546,23 +1628,21 @@ int td_noise_patches(td_engine* e, uint64_t base_seed, int n_windows, const int6
     }
     const int64_t tn = (int64_t)channels * tile_h * tile_w;
     Buf dseeds(new DevBuf()), dtiles(new DevBuf()), dindex(new DevBuf()), dorg(new DevBuf());
-    HIP_TRY(dseeds->alloc(seeds.size() * 8, false)); HIP_TRY(dtiles->alloc(seeds.size() * tn * 4, false));
-    HIP_TRY(dindex->alloc(index.size() * 4, false)); HIP_TRY(dorg->alloc(org.size() * 4, false));
+    HIP_TRY(dseeds->scratch(e->scratch, seeds.size() * 8)); HIP_TRY(dtiles->scratch(e->scratch, seeds.size() * tn * 4));
+    HIP_TRY(dindex->scratch(e->scratch, index.size() * 4)); HIP_TRY(dorg->scratch(e->scratch, org.size() * 4));
     hipStream_t st = e->stream;
-    HIP_TRY(hipMemcpyAsync(dseeds->p, seeds.data(), seeds.size() * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dindex->p, index.data(), index.size() * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dorg->p, org.data(), org.size() * 4, hipMemcpyHostToDevice, st));
+    int rc;
+    if ((rc = upload(e, dseeds->p, seeds.data(), seeds.size() * 8)) || (rc = upload(e, dindex->p, index.data(), index.size() * 4)) ||
+        (rc = upload(e, dorg->p, org.data(), org.size() * 4))) return rc;
     std::vector<Buf> hold;
     OutStage os;
-    int rc;
     if ((rc = out_device(e, out, (size_t)n_windows * channels * h * w * 4, hold, &os))) return rc;
     hipLaunchKernelGGL(noise_tiles_kernel, dim3((unsigned)seeds.size()), dim3(256), 0, st, (const uint64_t*)dseeds->p, (float*)dtiles->p, tn);
     hipLaunchKernelGGL(noise_gather_kernel, dim3((channels * h * w + 255) / 256, n_windows), dim3(256), 0, st, (const float*)dtiles->p, (const int*)dindex->p,
                        (const int*)dorg->p, (float*)os.dev, channels, h, w, tile_h, tile_w, scale);
     HIP_TRY(hipGetLastError());
     if ((rc = out_finish(e, os))) return rc;
-    HIP_TRY(hipStreamSynchronize(st));
-    return TD_OK;
+    return end_call(e, hold, !os.host);
 }
 
 // ---- blend
@@ -1617,9 +1697,8 @@ int td_blend_windows(td_engine* e, float* canvas, int C, int Hc, int Wc, int siz
     weight_window_host(size, ww);
     auto up = [&](const void* src, size_t bytes, Buf& b) -> int {
         b.reset(new DevBuf());
-        HIP_TRY(b->alloc(bytes, false));
-        HIP_TRY(hipMemcpyAsync(b->p, src, bytes, hipMemcpyHostToDevice, st));
-        return TD_OK;
+        HIP_TRY(b->scratch(e->scratch, bytes));
+        return upload(e, b->p, src, bytes);
     };
     Buf drow, dcol, drs, dcs, dtof, dww;
     int rc;
@@ -1635,7 +1714,7 @@ int td_blend_windows(td_engine* e, float* canvas, int C, int Hc, int Wc, int siz
     const bool cdev = is_device_ptr(canvas);
     if (!cdev) {
         cstage.reset(new DevBuf());
-        HIP_TRY(cstage->alloc(cbytes, false));
+        HIP_TRY(cstage->scratch(e->scratch, cbytes));
         dcanvas = (float*)cstage->p;
         if (accumulate) HIP_TRY(hipMemcpyAsync(dcanvas, canvas, cbytes, hipMemcpyHostToDevice, st));
     }
@@ -1643,8 +1722,7 @@ int td_blend_windows(td_engine* e, float* canvas, int C, int Hc, int Wc, int siz
                        (const int*)drow->p, (const int*)dcol->p, (const int*)drs->p, (const int*)dcs->p, (const int*)dtof->p, n_cols, accumulate);
     HIP_TRY(hipGetLastError());
     if (!cdev) HIP_TRY(hipMemcpyAsync(canvas, dcanvas, cbytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return TD_OK;
+    return end_call(e, hold, cdev && is_device_ptr(tiles));
 }
 
 int td_gather_regions(td_engine* e, int C, int size, int n_regions, int h, int w, int maxk, const int32_t* desc_host, int n_windows,
@@ -1664,21 +1742,20 @@ int td_gather_regions(td_engine* e, int C, int size, int n_regions, int h, int w
         HIP_TRY(ww->alloc(hw.size() * 4, false));
         HIP_TRY(hipMemcpy(ww->p, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
     }
-    const size_t dbytes = (size_t)n_regions * maxk * 3 * 4, pbytes = ((size_t)n_windows * 8 + 15) / 16 * 16, need = pbytes + dbytes;
-    if (!e->gather_stage || e->gather_stage->bytes < need) {
-        HIP_TRY(hipStreamSynchronize(st));   // a previous call's kernel may still read the old staging buffer
-        e->gather_stage.reset(new DevBuf());
-        HIP_TRY(e->gather_stage->alloc(std::max<size_t>(need * 2, 1 << 16), false));
-    }
-    unsigned char* stg = (unsigned char*)e->gather_stage->p;
-    // pageable sources: the runtime copies them to its own staging before returning, and the synchronous end of the call covers the rest
-    if (n_windows) HIP_TRY(hipMemcpyAsync(stg, window_ptrs_host, (size_t)n_windows * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(stg + pbytes, desc_host, dbytes, hipMemcpyHostToDevice, st));
+    const size_t dbytes = (size_t)n_regions * maxk * 3 * 4, pbytes = ((size_t)n_windows * 8 + 15) / 16 * 16;
+    Buf stage(new DevBuf());   // window pointers, then the descriptors
+    HIP_TRY(stage->scratch(e->scratch, pbytes + dbytes));
+    unsigned char* stg = (unsigned char*)stage->p;
+    int rc;
+    if ((rc = upload(e, stg, window_ptrs_host, (size_t)n_windows * 8)) || (rc = upload(e, stg + pbytes, desc_host, dbytes))) return rc;
     hipLaunchKernelGGL(regions_gather_kernel, dim3((unsigned)(((size_t)h * w + 255) / 256), (unsigned)n_regions), dim3(256), 0, st, (const float* const*)stg,
                        (const int*)(stg + pbytes), maxk, (const float*)ww->p, out, C, h, w, size);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));   // the descriptor staging is reused by the next call; window tensors may be released by the caller
-    return TD_OK;
+    // default: complete on return.  Option "async": enqueued; the window tensors are then the caller's to keep valid IN STREAM ORDER (a torch
+    // tensor released on the stream the engine runs on is: the allocator reuses its memory for later work of that stream only)
+    std::vector<Buf> hold;
+    hold.push_back(std::move(stage));
+    return end_call(e, hold, true);
 }
 
 int td_blend_normalize(td_engine* e, const float* canvas, int C, int Hc, int Wc, float scale, float* out) {
@@ -1712,13 +1789,13 @@ int td_resample2d(td_engine* e, const float* in, int C, int Hin, int Win, int Ho
     OutStage os;
     if ((rc = out_device(e, out, (size_t)C * Hout * Wout * 4, hold, &os))) return rc;
     Buf tmp(new DevBuf());
-    HIP_TRY(tmp->alloc((size_t)C * Hin * Wout * 4, false));
+    HIP_TRY(tmp->scratch(e->scratch, (size_t)C * Hin * Wout * 4));
     hipLaunchKernelGGL(resample_rows_kernel, grid1((size_t)C * Hin * Wout), dim3(256), 0, st, (const float*)din, (float*)tmp->p, C, Hin, Win, Wout, (const int*)dix, (const float*)dwx, Kx);
     hipLaunchKernelGGL(resample_cols_kernel, grid1((size_t)C * Hout * Wout), dim3(256), 0, st, (const float*)tmp->p, (float*)os.dev, C, Hin, Hout, Wout, (const int*)diy, (const float*)dwy, Ky);
     HIP_TRY(hipGetLastError());
     if ((rc = out_finish(e, os))) return rc;
-    HIP_TRY(hipStreamSynchronize(st));
-    return TD_OK;
+    hold.push_back(std::move(tmp));
+    return end_call(e, hold, !os.host && is_device_ptr(in));
 }
 
 int td_residual_plus(td_engine* e, const float* packed, const float* lowres_up, int Hp, int Wp, float res_mean, float res_std, float* out) {
@@ -1726,8 +1803,8 @@ int td_residual_plus(td_engine* e, const float* packed, const float* lowres_up, 
     if (!is_device_ptr(packed) || !is_device_ptr(lowres_up) || !is_device_ptr(out)) return fail(TD_ERR_ARG, "td_residual_plus: device buffers only");
     hipLaunchKernelGGL(residual_plus_kernel, grid1((size_t)Hp * Wp), dim3(256), 0, e->stream, packed, lowres_up, out, Hp * Wp, res_mean, res_std);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    return TD_OK;
+    std::vector<Buf> none;
+    return end_call(e, none, true);
 }
 
 int td_elev_finish(td_engine* e, const float* packed, const float* lowres_up, int Hp, int Wp, int oi, int oj, int h, int w, float res_mean, float res_std, float* out) {
@@ -1736,8 +1813,8 @@ int td_elev_finish(td_engine* e, const float* packed, const float* lowres_up, in
     if (oi < 0 || oj < 0 || oi + h > Hp || oj + w > Wp) return fail(TD_ERR_ARG, "td_elev_finish: crop outside the window");
     hipLaunchKernelGGL(elev_finish_kernel, grid1((size_t)h * w), dim3(256), 0, e->stream, packed, lowres_up, out, Hp, Wp, oi, oj, h, w, res_mean, res_std);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    return TD_OK;
+    std::vector<Buf> none;
+    return end_call(e, none, true);
 }
 
 int td_ddim_cfg_step(td_engine* e, const float* latent, const float* pred_uncond, const float* pred_cond, int64_t n, float guidance_scale, float alpha_t,

@@ -402,7 +402,9 @@ class DeviceWindowTensor(InfiniteTensor):
         for r, (b, p_) in enumerate(zip(bounds, per)):
             for k, c in enumerate(p_):
                 desc[r, k] = (order[c], c[1] * self.stride_hw + oy - b[1][0], c[2] * self.stride_hw + ox - b[2][0])
-        keep = list(tiles.values())   # the window tensors stay alive (and where they are) until the synchronous call returns
+        # the window tensors stay alive until the call returns; when the engine only enqueues (Engine.on_stream) they may be released earlier, which
+        # is safe in stream order: the allocator hands their memory to later work of the same stream only
+        keep = list(tiles.values())
         ptrs = np.asarray([t.data_ptr() for t in keep], dtype=np.uint64)
         out = torch.empty((n, self.channels + 1, h, w), dtype=torch.float32, device=self.device)
         import ctypes as _C
@@ -410,7 +412,6 @@ class DeviceWindowTensor(InfiniteTensor):
         return out
 
     def __getitem__(self, idx):
-        from .sampling import blend_windows
         lo, hi, squeeze = self._normalize_slices(idx)
         if any(h <= l for l, h in zip(lo, hi)):   # empty region: nothing to evaluate
             region = torch.zeros([h - l for l, h in zip(lo, hi)], dtype=torch.float32, device=self.device)
@@ -423,15 +424,9 @@ class DeviceWindowTensor(InfiniteTensor):
             for d in reversed(squeeze):   # integer indices on ANY dimension drop it, as in InfiniteTensor.__getitem__ and the full-channel path
                 sub = sub.squeeze(d)
             return sub
-        ctxs = sorted(self._windows_for(lo, hi))
-        tiles = self._ensure(ctxs)
-        rows = sorted({c[1] for c in ctxs})
-        cols = sorted({c[2] for c in ctxs})
-        oy, ox = self.output_window.offset[1], self.output_window.offset[2]
-        canvas = torch.empty((self.channels + 1, hi[1] - lo[1], hi[2] - lo[2]), dtype=torch.float32, device=self.device)
-        stack = torch.stack([tiles[c] for c in ctxs]).contiguous()
-        blend_windows(self.engine, canvas, stack, [(rows.index(c[1]), cols.index(c[2])) for c in ctxs],
-                      [r * self.stride_hw + oy - lo[1] for r in rows], [c * self.stride_hw + ox - lo[2] for c in cols], self.tile, accumulate=False)
+        # one region = a batch of one for the region-gather kernel (same per-pixel window order and arithmetic as td_blend_windows; no descriptor
+        # tables to build and upload per call, and nothing that ends the call with a host synchronisation when the engine runs enqueue-only)
+        canvas = self.gather_many([((0, self.channels + 1), (lo[1], hi[1]), (lo[2], hi[2]))])[0]
         for d in reversed([d for d in squeeze if d != 0]):
             canvas = canvas.squeeze(d)
         return canvas

@@ -93,10 +93,12 @@ def build_latent_stage(model, sigma_data=0.5, sigma_max=80.0, *, seed, cond_fn=N
         mk = lambda f, args, wins, tid: DeviceWindowTensor(channels, f, tile, stride, model.engine, args=args, args_windows=wins, tile_store=tile_store,
                                                             tensor_id=tid, batch_size=batch_size)
         if T == 1:
+            w_dev = w.to(dev)
+
             def f_t1d(ctxs, conds=None):
                 outs = None
                 for k, t in enumerate(ts):   # later phases read the window's own previous output (no blend): pack it the way a slice would arrive
-                    prevs = None if outs is None else [torch.cat([o * w.to(dev)[None], w.to(dev)[None]], dim=0) for o in outs]
+                    prevs = None if outs is None else torch.cat([outs * w_dev[None, None], w_dev[None, None].expand(outs.shape[0], 1, -1, -1)], dim=1)
                     outs = infer_raw(k, t, ctxs, prevs, conds)
                 return outs
             lat = mk(f_t1d, dsrc, dwin, f"{tensor_prefix}_T1")

@@ -85,6 +85,24 @@ def process_latent_conditioning(cond_img, histogram_raw, cond_means, cond_stds, 
     return torch.cat([p * (Cc / math.sqrt(p.shape[1]) * (1.0 / n)) for p in parts], dim=1).float()
 
 
+_DEV_CONST = {}
+
+
+def _dev_const(t, dev):
+    """small constant (statistics vectors, the histogram) as a device tensor, uploaded ONCE per (content, device): `.to(device)` of a pageable
+    host tensor waits for the copy, which would put a host synchronisation into every batch of an otherwise enqueue-only stage"""
+    t = torch.as_tensor(t, dtype=torch.float32)
+    if t.device == dev or t.is_cuda:
+        return t.to(dev)
+    key = (t.numpy().tobytes(), tuple(t.shape), str(dev))
+    v = _DEV_CONST.get(key)
+    if v is None:
+        if len(_DEV_CONST) > 64:
+            _DEV_CONST.clear()
+        v = _DEV_CONST[key] = t.to(dev)
+    return v
+
+
 def process_latent_conditioning_windows(cond_imgs, histogram_raw, cond_means, cond_stds, noise_level=0.0):
     """process_latent_conditioning applied to n windows ONE AT A TIME, as the reference's latent stage calls it (world_pipeline.py:1080-1088: a
     (1,7,4,4) image per window), evaluated for all windows at once: (n,7,4,4) -> (n,58) with a dozen tensor ops instead of ~30 per window.
@@ -95,11 +113,12 @@ def process_latent_conditioning_windows(cond_imgs, histogram_raw, cond_means, co
     dev = x.device
     cond_means = torch.as_tensor(cond_means, dtype=torch.float32)
     cond_stds = torch.as_tensor(cond_stds, dtype=torch.float32)
-    x = ((x - cond_means.view(1, -1, 1, 1).to(dev)) / cond_stds.view(1, -1, 1, 1).to(dev)).nan_to_num(float(cond_means[0]))
+    x = ((x - _dev_const(cond_means.view(1, -1, 1, 1), dev)) / _dev_const(cond_stds.view(1, -1, 1, 1), dev)).nan_to_num(float(cond_means[0]))
     clim = x[:, 2:6, 1:3, 1:3].mean(dim=(2, 3))
     B = x.shape[0]
-    nl = ((torch.as_tensor(noise_level, dtype=torch.float32) - 0.5) * np.sqrt(12)).to(dev)
-    hist = torch.as_tensor(histogram_raw, dtype=torch.float32).to(dev)
+    nl = (torch.as_tensor(noise_level, dtype=torch.float32) - 0.5) * np.sqrt(12)
+    nl = torch.full((1, 1), float(nl), dtype=torch.float32, device=dev) if nl.numel() == 1 and not nl.is_cuda else nl.to(dev)   # scalar: a fill, not an upload
+    hist = _dev_const(histogram_raw, dev)
     parts = [x[:, 0:1].flatten(1), x[:, 1:2].flatten(1), clim.flatten(1), x[:, 6:7].flatten(1), hist.view(-1, hist.shape[-1]).expand(B, -1), nl.view(-1, 1).expand(B, 1)]
     n = len(parts)
     Cc = math.sqrt(sum(p.shape[1] for p in parts) / (n * (1.0 / n) ** 2))

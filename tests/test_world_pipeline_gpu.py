@@ -249,3 +249,26 @@ def test_request_replica_mode_two_ranks_serve_the_same_world(td, models):
             assert torch.equal(got[k], ref[k]), k
     finally:
         eng.set_option("batch_invariant", 0)
+
+
+def test_enqueue_only_cascade_gives_the_bits_of_the_synchronous_one(td, models):
+    """Engine.on_stream (td_engine_set_stream + option "async"): every stage of the cascade -- noise, samplers, region gathers, resampling,
+    elevation / climate composition -- only ENQUEUES on the stream it shares with torch (host arrays go through the engine's pinned ring, scratch
+    through its stream-ordered pool) instead of completing on return.  Same world, same requests, same bits; and the window cache is small enough
+    that windows are evicted and released while work that reads them may still be queued."""
+    from terrain_diffusion_amd.engine import get_engine
+    eng = get_engine("cuda")
+    boxes = [(-40, 30, 150, 190), (90, 100, 260, 300), (-40, 30, 150, 190), (1000, -900, 1130, -720)]
+    ref_w = _world(td, models, cache_limit=2 * 2 ** 20)
+    ref = [ref_w.get(*b) for b in boxes]
+    ref_w.close()
+    w = _world(td, models, cache_limit=2 * 2 ** 20)
+    with eng.on_stream(torch.cuda.Stream()):
+        got = [w.get(*b) for b in boxes]        # nothing in here waits for the GPU
+        eng.synchronize()
+    torch.cuda.synchronize()
+    for b, r, g in zip(boxes, ref, got):
+        assert torch.equal(r["elev"], g["elev"]), b
+        assert torch.equal(r["climate"], g["climate"]), b
+    assert w.tile_store.evictions > 0
+    w.close()
