@@ -5,6 +5,7 @@ timeout 1800 python -m pytest tests -q -m gpu --durations=10 > gpurun_out/final_
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/final_smoke.txt 2>&1
 timeout 900 python bench.py > gpurun_out/final_bench_grid8.json 2> gpurun_out/final_bench_grid8.err
 timeout 600 python bench.py --workload cascade --steps 3 --warmup 1 > gpurun_out/final_bench_cascade.json 2> gpurun_out/final_bench_cascade.err
+timeout 600 python bench.py --workload cascade --steps 3 --warmup 1 --cascade-sync 1 --no-cpu-baseline > gpurun_out/final_bench_cascade_sync.json 2> gpurun_out/final_bench_cascade_sync.err
 timeout 600 python bench.py --workload cascade --dtype fp16 --steps 3 --warmup 1 > gpurun_out/final_bench_cascade_fp16.json 2> gpurun_out/final_bench_cascade_fp16.err
 timeout 600 python bench.py --workload tiles --steps 5 --warmup 2 --no-cpu-baseline --no-latency > gpurun_out/final_bench_tiles.json 2> gpurun_out/final_bench_tiles.err
 timeout 600 python bench.py --dtype fp16 --steps 5 --warmup 2 --no-cpu-baseline --no-latency > gpurun_out/final_bench_grid8_fp16.json 2> gpurun_out/final_bench_grid8_fp16.err
