@@ -26,7 +26,13 @@
 //           normalised against identical values any more; the mismatch is the mean of the rounding errors of the weights of one query --
 //           unbiased, <= 2^-9 relative and shrinking with the number of keys (measured 1.2-1.5e-3 rel-RMS against a bf16-operand reference
 //           on every shape of the test, 4096 keys at d = 40 with scale 0.173 included; bound in the test 4e-3).
+//       (3) deferred maximum (round 4, TD_ATTN_THR = 8): the reference point of a query's exponentials follows its running maximum only when
+//           some query of the wave has outgrown its own by more than 2^8; in between the probabilities of a tile are <= 2^8 instead of <= 1
+//           (fp32 accumulators, same bf16 relative precision, numerator and denominator share the reference point).  It removes the rescale
+//           of O -- a dependent, packed-multiply pass in front of the PV MFMAs -- from most tiles: +6 % / +3 % / +8 % at d = 40 / 64 / 128 on
+//           the 4096 x 4096 problem, rel-RMS against the fp64 reference 1.55e-3 -> 1.65e-3 (profiles/r04_attention_mfma_utilisation.txt).
 // K / V^T rows in LDS are padded to an odd number of 16-byte slots, which makes every 16-lane ds_read_b128 group conflict-free.
+// Consecutive MFMAs go to different accumulators (an instruction between two MFMAs on the SAME accumulator costs ~43 cycles, MI355X_MICROARCH.md).
 #include "conv_common.h"
 
 namespace td {
@@ -68,6 +74,15 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(const TIN* __restrict__ 
     }
 }
 
+#ifndef TD_ATTN_THR
+#define TD_ATTN_THR 8
+#endif
+#ifdef TD_ATTN_TRACE   // tools/attn_bench.hip -DTD_ATTN_TRACE: s_memtime stamps between the phases of a tile, summed per wave, dumped through out_b16
+#define TD_AT(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tr_[i] += t_ - tl_; tl_ = t_; }
+#else
+#define TD_AT(i)
+#endif
+
 // DP16 = Dp / 16 (k-steps of Q K^T), DM32 = Dm / 32 (row blocks of O^T)
 template <int DP16, int DM32, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __restrict__ Qp, const __bf16* __restrict__ Kp, const __bf16* __restrict__ Vt, float* __restrict__ out_f32,
@@ -75,8 +90,8 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
     constexpr int Dp = DP16 * 16, Dm = DM32 * 32, TK = 64;
     constexpr int KSL = (Dp / 8) | 1, KPITCH = KSL * 16;      // K rows: odd number of 16-byte slots
     constexpr int VPITCH = (TK / 8 + 1) * 16;                 // Vt rows: 64 keys = 8 slots -> 9
-    // K / V^T tiles are DOUBLE-buffered in LDS (round 3): tile t+1 travels global -> registers while tile t is computed and is written to the
-    // other buffer afterwards, so a tile costs one workgroup barrier instead of two
+    // K / V^T tiles are DOUBLE-buffered in LDS (round 3): tile t+1 travels global -> registers while tile t-1 is computed and is written to the
+    // other buffer at the top of tile t, so a tile costs one workgroup barrier instead of two
     __shared__ __attribute__((aligned(16))) unsigned char s_k[2][TK * KPITCH];
     __shared__ __attribute__((aligned(16))) unsigned char s_v[2][Dm * VPITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -126,34 +141,47 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
             if (e < VPIECES) *(u32x4*)(s_v[buf] + r * VPITCH + sl * 16) = vreg[it];
         }
     };
-    // two tiles ahead: tile t+1 sits in registers (requested a whole tile ago) while tile t+2 is requested at the top of tile t
-    u32x4 kreg2[KIT], vreg2[VIT];
+    // tile t+1 travels global -> registers during tile t-1 .. t and is written to the other LDS buffer at the TOP of tile t (every wave has passed the
+    // barrier that ended tile t-1, so that buffer's readers are done); the same registers then take the request for tile t+2.  (Round 3 kept
+    // two tiles in registers and copied one register set to the other every tile: 10 % of a tile's cycles in the phase trace.)  Loads are
+    // unconditional with the tile index clamped; the store of a tile that does not exist lands in a buffer nobody reads again.
+    const int nt_ = (Lk + TK - 1) / TK;
     load_tile(0);
     store_tile(0);
-    if (TK < Lk) load_tile(TK);
+    load_tile(nt_ > 1 ? TK : 0);
     __syncthreads();
     int buf = 0;
+#ifdef TD_ATTN_TRACE
+    unsigned long long tr_[6] = {0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     for (int k0 = 0; k0 < Lk; k0 += TK, buf ^= 1) {
-        const bool more = k0 + TK < Lk;
-#pragma unroll
-        for (int it = 0; it < KIT; ++it) kreg2[it] = kreg[it];
-#pragma unroll
-        for (int it = 0; it < VIT; ++it) vreg2[it] = vreg[it];
-        if (k0 + 2 * TK < Lk) load_tile(k0 + 2 * TK);   // lands during this tile and the next
+        TD_AT(5)
+        store_tile(buf ^ 1);
+        TD_AT(4)
+        { const int k2 = k0 + 2 * TK; load_tile(k2 < Lk ? k2 : (nt_ - 1) * TK); }
         const unsigned char* sk_ = s_k[buf];
         const unsigned char* sv_ = s_v[buf];
+        TD_AT(0)
         // ---- S^T = K Q^T for two 32-key blocks
         f32x16 s[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+        // consecutive MFMAs go to DIFFERENT accumulators: anything issued between two MFMAs on the same accumulator (a fragment read, here) costs
+        // ~43 cycles (MI355X_MICROARCH.md), between different ones ~6
 #pragma unroll
-            for (int ks = 0; ks < DP16; ++ks) {
+        for (int ks = 0; ks < DP16; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
                 const u32x4 kf = *(const u32x4*)(sk_ + (kb * 32 + l31) * KPITCH + ks * 32 + lh * 16);
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[ks]), s[kb], 0, 0, 0);
             }
-        }
+#ifdef TD_ATTN_TRACE
+        asm volatile("s_nop 0" :: "v"(s[0][0]), "v"(s[1][0]));   // the stamp waits for the MFMA results
+#endif
+        TD_AT(1)
         // ---- online softmax for this lane's query: keys of register r of block kb = k0 + 32 kb + 8 (r / 4) + 4 lh + r % 4.
         // The softmax is what bounds this kernel at small head dims (d = 40: 14 MFMAs = 448 matrix cycles against ~850 VALU cycles per tile
         // in round 2), so it is kept lean: no scaling multiply (folded into Q), the key mask only on the last, ragged tile, three-input
@@ -173,13 +201,16 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
 #pragma unroll
             for (int r = (kb == 0 ? 2 : 0); r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[kb][r]), s[kb][r + 1]);   // v_max3_f32
         mt = fmaxf(mt, __shfl_xor(mt, 32));
-        const float m_new = fmaxf(m_run, mt);
-        // the running maximum rarely moves after the first tiles: rescaling O and the denominator is skipped (wave-uniformly) when no query of
-        // the wave saw a new maximum
-        const bool moved = __builtin_amdgcn_ballot_w64(m_new > m_run) != 0;
+        // Deferred maximum (TD_ATTN_THR, in log2 units): the reference point m of a query only follows its running maximum when SOME query of
+        // the wave has outgrown its own by more than 2^THR -- then O and the denominator of the whole wave are rescaled; otherwise m stays and the
+        // probabilities of this tile are at most 2^THR instead of 1 (fp32 accumulators, bf16 relative precision: nothing overflows, numerator
+        // and denominator refer to the same m).  THR = 0 is the textbook form (rescale whenever any maximum grew: most tiles of random data).
+        const bool moved = __builtin_amdgcn_ballot_w64(mt > m_run + (float)TD_ATTN_THR) != 0;
+        const float m_new = moved ? fmaxf(m_run, mt) : m_run;
         const float alpha = moved ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.f;
-        f32x2 psum2 = {0.f, 0.f};
-        const f32x2 nm2 = {-m_new, -m_new};
+        // plain (unpacked) fp32 subtracts and adds: beside the partner wave's MFMAs a v_pk_add_f32 costs ~13 cycles more than a plain VALU op
+        // (MI355X_MICROARCH.md); two running sums (even / odd elements) keep the summation order of the packed form
+        float psum_e = 0.f, psum_o = 0.f;
         u32x4 pf[4];  // B fragments of the four 16-key steps: 8 probabilities each, already in contraction order
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -188,42 +219,46 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
                 bf16x8 pb;
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
-                    const f32x2 d = f32x2{s[kb][jj * 8 + e], s[kb][jj * 8 + e + 1]} + nm2;       // v_pk_add_f32
-                    const f32x2 p = {__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};  // inputs <= 0, flushing tiny results to 0 is fine
-                    psum2 = psum2 + p;                                                            // fp32 denominator (the numerator rounds to bf16: 2^-9 relative, unbiased)
-                    pb[e] = (__bf16)p.x; pb[e + 1] = (__bf16)p.y;
+                    const float p0 = __builtin_amdgcn_exp2f(s[kb][jj * 8 + e] - m_new);       // inputs <= 0, flushing tiny results to 0 is fine
+                    const float p1 = __builtin_amdgcn_exp2f(s[kb][jj * 8 + e + 1] - m_new);
+                    psum_e += p0; psum_o += p1;                                               // fp32 denominator (the numerator rounds to bf16: 2^-9 relative, unbiased)
+                    pb[e] = (__bf16)p0; pb[e + 1] = (__bf16)p1;
                 }
                 pf[kb * 2 + jj] = __builtin_bit_cast(u32x4, pb);
             }
-        l_run = l_run * alpha + (psum2.x + psum2.y);
+        l_run = l_run * alpha + (psum_e + psum_o);
         m_run = m_new;
+#ifdef TD_ATTN_TRACE
+        asm volatile("s_nop 0" :: "v"(pf[3]), "v"(l_run));
+#endif
+        TD_AT(2)
         // ---- O^T = alpha O^T + V^T P^T
+        if (moved) {
 #pragma unroll
-        for (int d = 0; d < DM32; ++d) {
-            if (moved) {
+            for (int d = 0; d < DM32; ++d)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            }
+        }
 #pragma unroll
-            for (int st4 = 0; st4 < 4; ++st4) {
+        for (int st4 = 0; st4 < 4; ++st4)
+#pragma unroll
+            for (int d = 0; d < DM32; ++d) {
                 const u32x4 vf = *(const u32x4*)(sv_ + (d * 32 + l31) * VPITCH + st4 * 32 + lh * 16);
                 o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf[st4]), o[d], 0, 0, 0);
             }
-        }
-        if (more) {   // tile t+1 (in kreg2 / vreg2 since the top of this tile) -> the other buffer, whose readers finished before the previous barrier
-#pragma unroll
-            for (int it = 0; it < KIT; ++it) {
-                const int e = tid + it * NTHR, r = e / (Dp / 8), sl = e % (Dp / 8);
-                if (e < KPIECES) *(u32x4*)(s_k[buf ^ 1] + r * KPITCH + sl * 16) = kreg2[it];
-            }
-#pragma unroll
-            for (int it = 0; it < VIT; ++it) {
-                const int e = tid + it * NTHR, r = e / (TK / 8), sl = e % (TK / 8);
-                if (e < VPIECES) *(u32x4*)(s_v[buf ^ 1] + r * VPITCH + sl * 16) = vreg2[it];
-            }
-        }
+#ifdef TD_ATTN_TRACE
+        asm volatile("s_nop 0" :: "v"(o[0][0]), "v"(o[DM32 - 1][0]));
+#endif
+        TD_AT(3)
         __syncthreads();
     }
+#ifdef TD_ATTN_TRACE
+    if (lane == 0 && out_b16) {
+        unsigned long long* tb = (unsigned long long*)out_b16 + ((((size_t)b * H + h) * gridDim.x + blockIdx.x) * NW + wave) * 8;
+        for (int i = 0; i < 6; ++i) tb[i] = tr_[i];
+    }
+    out_b16 = nullptr;
+#endif
     const float linv = 1.f / (l_run + __shfl_xor(l_run, 32));
     if (qok) {
 #pragma unroll
