@@ -259,6 +259,8 @@ def test_enqueue_only_cascade_gives_the_bits_of_the_synchronous_one(td, models):
     from terrain_diffusion_amd.engine import get_engine
     eng = get_engine("cuda")
     boxes = [(-40, 30, 150, 190), (90, 100, 260, 300), (-40, 30, 150, 190), (1000, -900, 1130, -720)]
+    # ... and enough further requests that the engine's pinned staging ring (2 x 2 MiB of descriptor / tap tables) wraps at least once
+    boxes += [(5000 + 173 * k, -3000 + 131 * (k % 7), 5000 + 173 * k + 140, -3000 + 131 * (k % 7) + 150) for k in range(44)]
     ref_w = _world(td, models, cache_limit=2 * 2 ** 20)
     ref = [ref_w.get(*b) for b in boxes]
     ref_w.close()
