@@ -117,16 +117,21 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
     constexpr int KPIECES = TK * (Dp / 8), VPIECES = Dm * (TK / 8);
     constexpr int KIT = (KPIECES + NTHR - 1) / NTHR, VIT = (VPIECES + NTHR - 1) / NTHR;
     u32x4 kreg[KIT], vreg[VIT];
+    // Every load is UNCONDITIONAL (piece index and key row clamped instead of predicated): a lane-predicated load sits in an exec-masked branch,
+    // and hipcc's wait-count pass then waits for the loads it has just issued (`s_waitcnt vmcnt(1)` right behind the third request in round 3's
+    // ISA: the "prefetch" of a tile stalled the wave for a whole L2 round trip, 19 % of a tile's cycles at d = 128).  A clamped K row is a copy of
+    // the last key: its logits are masked in the ragged last tile like any key >= Lk; surplus pieces are loaded and never stored.
     auto load_tile = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < KIT; ++it) {
-            const int e = tid + it * NTHR, r = e / (Dp / 8), sl = e % (Dp / 8);
-            kreg[it] = (e < KPIECES && k0 + r < Lk) ? *(const u32x4*)(kbase + (long)(k0 + r) * Dp + sl * 8) : u32x4{0u, 0u, 0u, 0u};
+            const int e0 = tid + it * NTHR, e = e0 < KPIECES ? e0 : KPIECES - 1, r = e / (Dp / 8), sl = e % (Dp / 8);
+            const int row = k0 + r < Lk ? k0 + r : Lk - 1;
+            kreg[it] = *(const u32x4*)(kbase + (long)row * Dp + sl * 8);
         }
 #pragma unroll
         for (int it = 0; it < VIT; ++it) {
-            const int e = tid + it * NTHR, r = e / (TK / 8), sl = e % (TK / 8);
-            vreg[it] = e < VPIECES ? *(const u32x4*)(vbase + (long)r * Lkp + k0 + sl * 8) : u32x4{0u, 0u, 0u, 0u};   // Lkp is a multiple of 64, padding keys are zero
+            const int e0 = tid + it * NTHR, e = e0 < VPIECES ? e0 : VPIECES - 1, r = e / (TK / 8), sl = e % (TK / 8);
+            vreg[it] = *(const u32x4*)(vbase + (long)r * Lkp + k0 + sl * 8);   // Lkp is a multiple of 64, padding keys are zero
         }
     };
     auto store_tile = [&](int buf) {
