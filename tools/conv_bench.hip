@@ -86,6 +86,11 @@ int main(int argc, char** argv) {
             CK(hipEventRecord(e0, st)); CK(L(p)); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); float t; CK(hipEventElapsedTime(&t, e0, e1)); acc += t; }
         printf("   cold caches (mode %d): %.1f us (hot loop above: %.1f us)\n", mode, acc / reps * 1e3, ms * 1e3); CK(hipFree(fl));
     }
+    if (const char* df = getenv("TD_DUMP")) {   // the output of one launch, for comparing two builds of the kernels bit by bit (cmp)
+        CK(hipMemset(out, 0, M * Cout * 2)); CK(L(p)); CK(hipStreamSynchronize(st));
+        std::vector<uint16_t> ho(M * Cout); CK(hipMemcpy(ho.data(), out, ho.size() * 2, hipMemcpyDeviceToHost));
+        FILE* fp = fopen(df, "wb"); if (fp) { fwrite(ho.data(), 2, ho.size(), fp); fclose(fp); }
+    }
     double flop = 2.0 * M * Cout * ((double)Cin * taps + (double)Cin2 * taps2);
     printf("N%d %dx%d Cin%d Cout%d taps%d xform%d bn%d ks%d fl%d epi%d stg%d ch%d : %.1f us  %.1f TFLOP/s (%.1f%% of 2500)  wgs=%d\n", N, H, W, Cin, Cout, taps, xform, bn, ksplit, flavor, epi, stagger, chain, ms * 1e3,
            flop / ms / 1e9, flop / ms / 1e9 / 25.0, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * ksplit);
