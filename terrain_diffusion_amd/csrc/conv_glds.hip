@@ -25,8 +25,13 @@ namespace td {
 #endif
 
 // DMA1: the instantiation that streams 1x1 segments by LDS-DMA (launch_glds_cfg picks it per launch; the plain instantiation is untouched by it)
+#ifdef TD_BN64_OCC3   // experiment (tools/conv_bench.hip): three 4-wave workgroups of the 64-cout tile per CU (<= 168 VGPRs, 51.5 KB of LDS each)
+#define TD_GLDS_MIN_WAVES(BN, W) ((BN) == 64 && (W) == 4 ? 3 : ((W) + 3) / 4 < 2 ? 2 : ((W) + 3) / 4)
+#else
+#define TD_GLDS_MIN_WAVES(BN, W) (((W) + 3) / 4 < 2 ? 2 : ((W) + 3) / 4)
+#endif
 template <typename T, int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N, bool DMA1 = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4 < 2 ? 2 : (WAVES_M * WAVES_N + 3) / 4) void conv_glds_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, TD_GLDS_MIN_WAVES(BN, WAVES_M * WAVES_N)) void conv_glds_kernel(const ConvParams p) {
     typedef typename Half<T>::x8 hx8;
     typedef typename Half<T>::x4 hx4;
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
@@ -50,12 +55,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
     // slots per MFMA per SIMD, MI355X guide: every address instruction in the loop is paid in full).
     constexpr int PITCH = 144;
     constexpr int A_BASE = RING * B_BYTES, A_BYTES = NPATCH * PITCH;
+    // round 5: the modulation rows c[n][co0 .. co0 + BN) of the tile's images (EPI_EMB_SILU) are staged in LDS by the prologue -- the epilogue then
+    // reads them with ds_read_b128 instead of 2 x NT x 2 global loads per pixel row group between the last MFMA and the first store.  Behind
+    // everything else (patch + 1/rms table, or the 1x1 stage buffers of the DMA instantiation).
+    constexpr int CV_BASE = A_BASE + ((A_BYTES + NPATCH * 4 > (DMA1 ? NST * STAGE_BYTES : 0) ? A_BYTES + NPATCH * 4 : NST * STAGE_BYTES) + 15) / 16 * 16;
+    constexpr int NU = NT * 2;   // epilogue units (8 couts of one pixel) per 32-pixel row group
+    static_assert(NIMG * BN <= NTHR, "modulation rows: one element per thread");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "tile shape");
     static_assert((RING - 1) * B_BYTES + (NT - 1) * 4096 + 128 < 65536 && 2 * PW * PITCH + 2 * PITCH + 128 < 65536, "ds_read offset field");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // the ONLY LDS object: its offset is 0
     unsigned char* s_a = smem + A_BASE;
     float* s_rn = (float*)(smem + A_BASE + A_BYTES);
+    float* s_cv = (float*)(smem + CV_BASE);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -78,7 +90,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
     unsigned k_d0 = p.sb_d0, k_m0 = p.sb_m0, k_d1 = p.sb_d1, k_m1 = p.sb_m1, k_m2 = p.sb_m2, k_m3 = p.sb_m3, k_g8 = p.sb_grid8, k_grid = p.sb_grid;
     int k_tx = p.tiles_x, k_ty = p.tiles_y, k_rev = p.reverse, k_ks = p.ksplit, k_kg = p.kgroups, k_cpad = p.CoutPad, k_N = p.N, k_H = p.H, k_W = p.W;
     const unsigned char* k_wpack = (const unsigned char*)p.wpack;   // only ever the scalar base of an LDS-DMA statement: no address space to lose
-    asm volatile("" : "+s"(k_cpad), "+s"(k_N), "+s"(k_H), "+s"(k_W), "+s"(k_wpack));
+    int k_epi = p.epi, k_Cout = p.Cout, k_of32 = p.out_f32, k_cvs = p.cvec_stride;   // round 5: the epilogue kind is known before the K loop
+    const bool k_hres = p.res != nullptr;
+    asm volatile("" : "+s"(k_cpad), "+s"(k_N), "+s"(k_H), "+s"(k_W), "+s"(k_wpack), "+s"(k_epi), "+s"(k_Cout), "+s"(k_of32), "+s"(k_cvs));
     asm volatile("" : "+s"(k_d0), "+s"(k_m0), "+s"(k_d1), "+s"(k_m1), "+s"(k_m2), "+s"(k_m3), "+s"(k_g8), "+s"(k_grid), "+s"(k_tx), "+s"(k_ty), "+s"(k_rev), "+s"(k_ks), "+s"(k_kg));
     unsigned ubid = blockIdx.x;
 #ifndef TD_NO_XCD_REMAP
@@ -176,6 +190,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
             }                                                                                          \
         }                                                                                              \
     }
+    // Round 5: the residual runs of the wide epilogue (EPI_RESIDUAL: 16 bytes per lane and unit, MT * NU units) are requested at tap 0 of the LAST
+    // 3x3 K-group into the patch-prefetch registers `av`, which are dead there -- exactly A_ITERS loads in the slot of TD_LOAD_A, so the counted
+    // waits of the tap loop hold unchanged and no register is added to the loop.  Index-clamped and unconditional (a pixel outside the image or a
+    // cout tile past Cout reads a valid address nobody uses).  Units beyond A_ITERS (bn 128: 8 > 6) are fetched at the top of the epilogue.
+    // (never in the DMA instantiation: its launches end in 1x1 K-groups by construction)
+    const bool r_want = !DMA1 && k_ks == 1 && !k_of32 && (k_Cout & 7) == 0 && k_epi == EPI_RESIDUAL && k_hres;
+    bool r_pref = false;   // `av` holds the residual runs
+    int r_off[MT];
+#define TD_R_ADDR()                                                                                                   \
+    {                                                                                                                 \
+        const int rHs_ = p.res_Hs, rWs_ = p.res_Ws, rrs_ = p.res_resample, rcs_ = p.res_cstride;                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_) {                                                           \
+            int img_, ty_, tx_;                                                                                       \
+            frag_pixel<TW, TPIX>(wm * WM + i_ * 32, l31, img_, ty_, tx_);                                             \
+            const int n_ = n0 + img_, y_ = y0 + ty_, x_ = x0 + tx_;                                                   \
+            const int sp_ = (n_ < k_N && y_ < k_H && x_ < k_W) ? src_pixel(n_, y_, x_, rHs_, rWs_, rrs_) : 0;         \
+            r_off[i_] = sp_ * rcs_ + co0 + wn * WN + 8 * lh;                                                          \
+        }                                                                                                             \
+    }
+#define TD_R_UNIT(Q) (*(const u32x4*)((const T*)p.res + r_off[(Q) / NU] + ((co0 + wn * WN + (((Q) % NU) >> 1) * 32 < k_Cout) ? (((Q) % NU) >> 1) * 32 + ((Q) & 1) * 16 : 0)))
+#define TD_LOAD_R()                                                                                                   \
+    {                                                                                                                 \
+        TD_R_ADDR();                                                                                                  \
+        _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) av[it_] = TD_R_UNIT(it_ < MT * NU ? it_ : MT * NU - 1); \
+        r_pref = true;                                                                                                \
+    }
     // DMA instantiation, K range starting in a 1x1 segment (a pure 1x1 conv, or a later split-K slice): nothing is staged through registers
     const bool dma_first = DMA1 && p.seg[seg_first].taps != 9;
     if (!dma_first) {
@@ -197,6 +237,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
                 rn = pixel_rn(rn_sumsq, rn_parts, npix, src_pixel(n, y, x, rn_Hs, rn_Ws, rn_res), rn_invc);
             s_rn[pp] = rn;
         }
+    }
+
+    if (k_epi == EPI_EMB_SILU && tid < NIMG * BN) {   // modulation rows of this tile (zero where there is no image / no cout)
+        const int im = tid / BN, c = tid - im * BN;
+        const bool v = n0 + im < k_N && co0 + c < k_Cout;
+        s_cv[tid] = v ? p.cvec[(size_t)(n0 + im) * k_cvs + co0 + c] : 0.f;
     }
 
     // ---- MFMA operand addressing: weights = A operand (rows = couts), activations = B operand (cols = pixels).
@@ -259,18 +305,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
         __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);                                             \
         TD_T(tA_);                                                                                           \
         /* tile k+1 (issued one tap ago) has landed; only tap 0's patch loads may be younger (tap 1) */      \
-        if ((TAPIDX) == 1 && has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS) : "memory");        \
+        if ((TAPIDX) == 1 && (has_next || r_now)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS) : "memory"); \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
         /* LDS returns in order: everything older than the two k-steps just requested is back */             \
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (NT + MT)) : "memory");                               \
         __builtin_amdgcn_s_barrier();                                                                        \
         asm volatile("" ::: "memory");                                                                       \
         TD_T(tB_); TD_TACC(tr_wait, tA_, tB_);                                                               \
-        if ((TAPIDX) == 3 && has_next) {                                                                     \
+        if ((TAPIDX) == 3 && (has_next || r_now)) {                                                          \
             _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) asm volatile("" : "+v"(av[it_]));      \
         }                                                                                                    \
         TD_ABL_BLOAD(TD_GLDS_B(((SLOT) + 2) % RING));                                                        \
-        if ((TAPIDX) == 0 && has_next) TD_LOAD_A(chunk + 1);                                                 \
+        if ((TAPIDX) == 0) { if (has_next) TD_LOAD_A(chunk + 1) else if (r_now) TD_LOAD_R() }                \
         TD_FRAG_MFMA(wfA_, xfA_);                                                                            \
         if ((TAPIDX) < 8) TD_FRAG_READ(wfA_, xfA_, ((SLOT) + 1) % RING, 0, TOFF_NEXT);                       \
         TD_FRAG_MFMA(wfB_, xfB_);                                                                            \
@@ -426,6 +472,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
         }
         for (int chunk = (seg == seg_first ? chunk_first : 0); chunk < seg_nchunks && gidx < g1; ++chunk, ++gidx) {
             const bool has_next = chunk + 1 < seg_nchunks && gidx + 1 < g1;
+            const bool r_now = r_want && gidx + 1 == g1;   // last K-group of the launch (never true in front of 1x1 groups)
             if (DMA1 || seg_taps == 9) {  // slot == 0 here: the host orders 3x3 segments before 1x1 segments, and RING divides 9
                 TD_GROUP_ENTRY();
                 TD_TAPP(0, 0, TD_TOFF(0), TD_TOFF(1)); TD_TAPP(1, 1, TD_TOFF(1), TD_TOFF(2)); TD_TAPP(2, 2, TD_TOFF(2), TD_TOFF(3));
@@ -507,6 +554,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
         }
         return;
     }
+    const bool has_res = e_epi == EPI_RESIDUAL && e_hres;
+    constexpr int NRX = MT * NU > A_ITERS ? MT * NU - A_ITERS : 1;
+    u32x4 rx[NRX];
+#pragma unroll
+    for (int q = 0; q < NRX; ++q) rx[q] = u32x4{0u, 0u, 0u, 0u};
+    if (wide && has_res) {
+        if (!r_pref) TD_LOAD_R()   // the launch ended in 1x1 K-groups (attention projection): nothing was requested yet
+        else if (MT * NU > A_ITERS) TD_R_ADDR()
+        if constexpr (MT * NU > A_ITERS) {
+#pragma unroll
+            for (int q = 0; q < NRX; ++q) rx[q] = TD_R_UNIT(A_ITERS + q);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         int img, ty, tx;
@@ -523,49 +583,43 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N + 3) / 4
             const int cobase = co0 + wn * WN + 4 * lh;
             const int sp = (e_epi == EPI_RESIDUAL && e_hres) ? src_pixel(n, y, x, e_rHs, e_rWs, e_rrs) : 0;
             if (wide) {
-                // units of 8 couts (shared arithmetic: epi_unit8); the operand of unit u+1 is requested before unit u is computed
+                // units of 8 couts (shared arithmetic: epi_unit8).  Round 5: no operand is waited for inside the unit loop -- the modulation rows
+                // come from LDS (s_cv, staged by the prologue), the residual runs were requested during the last K-group (`av`, TD_LOAD_R) or, for
+                // the units `av` does not hold, at the top of the epilogue (`rx`); the loop is straight-line code per epilogue kind (a load in a
+                // wave-uniform branch between the stores of the previous unit made hipcc wait for it right behind its issue).
                 const size_t pix = ((size_t)n * k_H + y) * k_W + x;
                 T* orow = (T*)p.out + pix * e_ocs + co0 + wn * WN + 8 * lh;
-                const T* rrow = (const T*)p.res + (size_t)sp * e_rcs + co0 + wn * WN + 8 * lh;
-                const float* crow = p.cvec + (size_t)n * e_cvs + cobase;
                 const float rs = e_rsc * rn;
-                const bool has_res = e_epi == EPI_RESIDUAL && e_hres, want_ss = e_hoss, want_o2 = e_ho2;
+                const bool want_ss = e_hoss, want_o2 = e_ho2;
                 const SiluK k_o2 = silu_k(e_o2s);
-                constexpr int NU = NT * 2;
-                f32x4 ca[2] = {}, cb[2] = {};
-                u32x4 rw[2] = {};
-                auto fetch = [&](int u, int s_) {
-                    const int j = u >> 1, m = u & 1;
-                    const bool in = co0 + wn * WN + j * 32 < e_Cout;
-#ifdef TD_ABL_EPI_NOLD  // tools/conv_bench.hip ablations of the epilogue: operand loads / arithmetic / stores removed one at a time
-                    (void)in; ca[s_] = f32x4{1.f, 1.f, 1.f, 1.f}; cb[s_] = ca[s_]; rw[s_] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-#else
-                    if (e_epi == EPI_EMB_SILU) { ca[s_] = *(const f32x4*)(crow + (in ? j * 32 + m * 16 : 0)); cb[s_] = *(const f32x4*)(crow + (in ? j * 32 + m * 16 : 0) + 8); }
-                    else if (has_res) rw[s_] = *(const u32x4*)(rrow + (in ? j * 32 + m * 16 : 0));
-#endif
-                };
-                fetch(0, 0);
+                auto body = [&](auto KIND) {
+                    constexpr int K = decltype(KIND)::value;
+                    f32x4 ca[NU], cb[NU];
+                    u32x4 rw[NU];
 #pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    const int j = u >> 1, m = u & 1, s_ = u & 1;
-                    if (u + 1 < NU) fetch(u + 1, s_ ^ 1);
-                    if (co0 + wn * WN + j * 32 >= e_Cout) continue;
-                    const f32x4 va = {acc[i][j][8 * m + 0], acc[i][j][8 * m + 1], acc[i][j][8 * m + 2], acc[i][j][8 * m + 3]};
-                    const f32x4 vb = {acc[i][j][8 * m + 4], acc[i][j][8 * m + 5], acc[i][j][8 * m + 6], acc[i][j][8 * m + 7]};
-                    u32x4 o, o2;
-#ifdef TD_ABL_EPI_NOVALU
-                    o = u32x4{__builtin_bit_cast(unsigned, va[0]) ^ rw[s_][0], __builtin_bit_cast(unsigned, va[1]) ^ __builtin_bit_cast(unsigned, ca[s_][0]), __builtin_bit_cast(unsigned, vb[0]), __builtin_bit_cast(unsigned, vb[1])};
-                    o2 = u32x4{__builtin_bit_cast(unsigned, va[2]), __builtin_bit_cast(unsigned, va[3]), __builtin_bit_cast(unsigned, vb[2]), __builtin_bit_cast(unsigned, vb[3]) ^ __builtin_bit_cast(unsigned, cb[s_][0])};
-#else
-                    epi_unit8<T>(e_epi, has_res, e_clip, want_ss, want_o2, va, vb, ca[s_], cb[s_], rw[s_], rs, k_o2, o, o2, ssj[j]);
-#endif
-#ifdef TD_ABL_EPI_NOST
-                    if (o[0] == 0x12345678u && o2[1] == 0x9abcdef0u && (!want_o2 || o2[0] == 77u)) *(u32x4*)(orow + j * 32 + m * 16) = o;
-#else
-                    *(u32x4*)(orow + j * 32 + m * 16) = o;
-                    if (want_o2) *(u32x4*)((T*)p.out2 + (orow - (T*)p.out) + j * 32 + m * 16) = o2;
-#endif
-                }
+                    for (int u = 0; u < NU; ++u) {
+                        ca[u] = f32x4{0.f, 0.f, 0.f, 0.f}; cb[u] = ca[u]; rw[u] = u32x4{0u, 0u, 0u, 0u};
+                        if constexpr (K == 1) {
+                            const float* c_ = s_cv + img * BN + wn * WN + (u >> 1) * 32 + (u & 1) * 16 + 4 * lh;
+                            ca[u] = *(const f32x4*)c_; cb[u] = *(const f32x4*)(c_ + 8);
+                        }
+                        if constexpr (K == 2) rw[u] = i * NU + u < A_ITERS ? av[i * NU + u < A_ITERS ? i * NU + u : 0] : rx[i * NU + u >= A_ITERS ? i * NU + u - A_ITERS : 0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int j = u >> 1, m = u & 1;
+                        if (co0 + wn * WN + j * 32 >= e_Cout) continue;
+                        const f32x4 va = {acc[i][j][8 * m + 0], acc[i][j][8 * m + 1], acc[i][j][8 * m + 2], acc[i][j][8 * m + 3]};
+                        const f32x4 vb = {acc[i][j][8 * m + 4], acc[i][j][8 * m + 5], acc[i][j][8 * m + 6], acc[i][j][8 * m + 7]};
+                        u32x4 o, o2;
+                        epi_unit8<T>(e_epi, has_res, e_clip, want_ss, want_o2, va, vb, ca[u], cb[u], rw[u], rs, k_o2, o, o2, ssj[j]);
+                        *(u32x4*)(orow + j * 32 + m * 16) = o;
+                        if (want_o2) *(u32x4*)((T*)p.out2 + (orow - (T*)p.out) + j * 32 + m * 16) = o2;
+                    }
+                };
+                if (e_epi == EPI_EMB_SILU) body(std::integral_constant<int, 1>{});
+                else if (has_res) body(std::integral_constant<int, 2>{});
+                else body(std::integral_constant<int, 0>{});
             } else {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
@@ -616,8 +670,8 @@ static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
     constexpr int NPATCH = NIMG * (TH + 2) * (TW == 8 ? 12 : TW + 2);
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
     constexpr size_t RING_BYTES = 3 * (size_t)(((BN * 128 + NTHR * 16 - 1) / (NTHR * 16)) * NTHR * 16);
-    constexpr size_t LDS_STAGES = RING_BYTES + (size_t)(WAVES_M * WAVES_N >= 8 ? 3 : 2) * (NIMG * TH * TW * 128);   // 1x1 stage buffers over the patch (+ s_rn)
-    size_t lds = (size_t)NPATCH * 144 + RING_BYTES + NPATCH * 4 + (size_t)g_bench_extra_lds;
+    constexpr size_t STAGES = (size_t)(WAVES_M * WAVES_N >= 8 ? 3 : 2) * (NIMG * TH * TW * 128);   // 1x1 stage buffers over the patch (+ s_rn)
+    constexpr size_t PATCH_RN = (size_t)NPATCH * 144 + NPATCH * 4, CV_BYTES = (size_t)NIMG * BN * 4;   // the kernel's CV_BASE follows the same rule
     bool seen1 = false;  // the kernel's compile-time ring slots need every 3x3 segment to start on a multiple of 3 K-steps
     for (int s = 0; s < p.nseg; ++s) { if (p.seg[s].taps == 9 && seen1) return hipErrorInvalidValue; if (p.seg[s].taps != 9) seen1 = true; }
     // LDS-DMA streaming of the 1x1 segments (pure 1x1 convs and split-K slices that start inside a 1x1 segment included): no input transform on
@@ -627,7 +681,7 @@ static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
     for (int s = 0; s < p.nseg && dma; ++s) if (p.seg[s].taps != 9 && p.seg[s].xform != 0) dma = false;
     const int grid = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * p.ksplit;
     constexpr bool HAS_DMA = true;
-    if (dma) lds = std::max(lds, LDS_STAGES + (size_t)g_bench_extra_lds);
+    const size_t lds = RING_BYTES + ((dma ? std::max(PATCH_RN, STAGES) : PATCH_RN) + 15) / 16 * 16 + CV_BYTES + (size_t)g_bench_extra_lds;
     pd.dma1x1 = dma ? 1 : 0;
     {   // workgroup-id decode constants of the kernel prologue
         const int mtiles_ = p.tiles_x * p.tiles_y * p.img_groups;

@@ -476,6 +476,7 @@ static hipError_t launch_pp_cfg(const ConvParams& p, int n_cus, hipStream_t st) 
 // bn 128 -> waves 4x2 (64 px x 64 co per wave), bn 96 -> 8x1 (32 px x 96 co).  Preconditions are the caller's (see conv_pp_eligible).
 template <typename T>
 static hipError_t launch_conv_pp_t(const ConvParams& p, int bn, int n_cus, bool dmap, hipStream_t st) {
+    if (bn == 64) return dmap ? launch_pp_cfg<T, 64, 8, 1, true>(p, n_cus, st) : launch_pp_cfg<T, 64, 8, 1, false>(p, n_cus, st);
     if (dmap) return bn == 128 ? launch_pp_cfg<T, 128, 4, 2, true>(p, n_cus, st) : launch_pp_cfg<T, 96, 8, 1, true>(p, n_cus, st);
     return bn == 128 ? launch_pp_cfg<T, 128, 4, 2, false>(p, n_cus, st) : launch_pp_cfg<T, 96, 8, 1, false>(p, n_cus, st);
 }

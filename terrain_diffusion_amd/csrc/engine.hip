@@ -270,7 +270,9 @@ struct ConvWeights {
     int cout = 0, cout_pad = 0;
     Buf packed;
     int ksteps = 0;
-    Buf packed_sb;             // 16-bit modes: the same weights in MFMA-fragment order for the small-batch flavour (conv_sb.hip)
+    Buf packed_sb;             // 16-bit modes: the same weights in MFMA-fragment order for the small-batch flavour (conv_sb.hip); made the first
+                               // time a plan puts this op on that flavour (ensure_packed_sb): never with option "sb" = 0 / "batch_invariant" = 1
+    size_t packed_bytes = 0;   // bytes of weights in `packed` (without its tail padding)
     int sb_n3 = 0, sb_g1 = 0;  // its leading 3x3 K-groups / trailing 1x1 K-groups (sb_n3 < 0: segment order not supported by that flavour)
 };
 
@@ -291,6 +293,7 @@ struct Op {
                                // 3: persistent ping-pong kernel (conv_pp.hip); 4: small-batch kernel, K split over the waves of a workgroup (conv_sb.hip)
     int sb_mt = 2, sb_nt = 2;  // flavour 4: 32-pixel / 32-cout MFMA blocks per workgroup
     int cvec_off = -1;         // EPI_EMB_SILU: offset of this block's c vector
+    double k_alg = 0.0;        // sum over the K-segments of (real input channels x taps): the algorithmic K of the op (profile labels, roofline FLOP)
     int out_C = 0, out_H = 0, out_W = 0;  // output tensor geometry (debug read-back)
     // ATTN
     const void* qkv = nullptr; void* att = nullptr; int tokens = 0, C = 0;
@@ -496,13 +499,18 @@ static int pack_conv(td_unet* u, ConvWeights& cw) {
             if (s.taps == 9) { if (seen1) { cw.sb_n3 = -1; break; } cw.sb_n3 += s.c_pad / chunk; }
             else { seen1 = true; cw.sb_g1 += s.c_pad / chunk; }
         }
-        if (cw.sb_n3 >= 0) {
-            cw.packed_sb.reset(new DevBuf());
-            HIP_TRY(cw.packed_sb->alloc(total * u->esize() + 16384, true));
-            HIP_TRY(launch_sb_repack(cw.packed->p, cw.packed_sb->p, cw.cout_pad, cw.sb_n3, cw.sb_g1, nullptr));
-            HIP_TRY(hipDeviceSynchronize());
-        }
     }
+    cw.packed_bytes = total * u->esize();
+    return TD_OK;
+}
+
+// Fragment-order copy of an op's weights for the small-batch flavour, on first use (the planner calls this when it puts the op on conv_sb): +0.5 GB
+// for the 30m base model when every conv of a single-tile forward runs on that flavour, nothing for models that never leave the throughput flavour.
+static int ensure_packed_sb(td_unet* u, ConvWeights& cw) {
+    if (cw.packed_sb || cw.sb_n3 < 0) return TD_OK;
+    cw.packed_sb.reset(new DevBuf());
+    HIP_TRY(cw.packed_sb->alloc(cw.packed_bytes + 16384, true));   // (alloc synchronises behind its zero fill)
+    HIP_TRY(launch_sb_repack(cw.packed->p, cw.packed_sb->p, cw.cout_pad, cw.sb_n3, cw.sb_g1, u->eng->stream));
     return TD_OK;
 }
 
@@ -717,6 +725,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                 d.sumsq = s.t->sumsq; d.nparts = s.t->nparts; d.inv_c = 1.f / (float)s.t->C;
             }
             kgroups += d.C / chunk;
+            op.k_alg += (double)cw.segs[i].c_real * s.taps;   // e.g. 6 of the input conv's 64 padded channels
             if (cw.segs[i].c_pad != d.C || cw.segs[i].taps != d.taps) return fail(TD_ERR_STATE, "segment/weight mismatch: " + label);
         }
         p.wpack = cw.packed->p;
@@ -759,8 +768,12 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                 if (t96 < 0.9 * t128) bn2 = 96;
             }
             // (grids below "glds_min_wgs" used to fall to the per-tap flavour; with the small-batch flavour available they enter here and take it)
-            const bool sb_avail = u->bf16 && !inv && u->eng->option("sb", 1) != 0 && cw.sb_n3 >= 0 && cw.packed_sb;
-            if (u->bf16 && bn2 && u->eng->option("glds", 1) && (inv || sb_avail || mt2 * (cw.cout_pad / bn2) >= u->eng->option("glds_min_wgs", 8))) {
+            // The small-batch flavour's own conditions are evaluated HERE: a grid below "glds_min_wgs" may only enter the branch when that flavour
+            // will really take it -- otherwise it falls to the per-tap flavour as before (it used to stay on conv_glds with a tiny grid)
+            bool sb_avail = u->bf16 && !inv && u->eng->option("sb", 1) != 0 && cw.sb_n3 >= 0;
+            for (const SegSpec& sg : segs) if (sg.taps != 9 && sg.xform != 0) sb_avail = false;   // its 1x1 K-groups go straight from global memory to the MFMA
+            const bool sb_takes = sb_avail && bn2 && mt2 * (cw.cout_pad / bn2) * 2 <= (variant ? 512 : 256) && mt2 * (cw.cout_pad / bn2) <= u->eng->option("sb_max_glds_wgs", 1 << 30);
+            if (u->bf16 && bn2 && u->eng->option("glds", 1) && (inv || sb_takes || mt2 * (cw.cout_pad / bn2) >= u->eng->option("glds_min_wgs", 8))) {
                 op.flavor = 2; op.bn = bn2; op.glds_variant = variant;
                 int TH2 = variant ? 8 : (op.narrow ? 8 : 16);
                 const int NIMG2 = op.narrow ? (variant ? 2 : 4) : 1;
@@ -805,10 +818,9 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                 // additionally split K over workgroups, 64 x 32 tiles, ~224 workgroups in all: the partial planes there are small (64 - 256 pixels)
                 // and the reduce launch costs less than the weight stream gains (tools/sb_splitk.sh: 8x8 1536->768 39 -> 17 us cold).
                 // Not in batch_invariant mode (conv_glds stays pinned): the K order differs, so the choice must not depend on the batch.
-                if (op.flavor == 2 && sb_avail && wgs * 2 <= slots && wgs <= u->eng->option("sb_max_glds_wgs", 1 << 30)) {
-                    bool ok1 = true;
-                    for (int i = 0; i < p.nseg; ++i) if (p.seg[i].taps != 9 && p.seg[i].xform != 0) ok1 = false;
-                    if (ok1) {
+                if (op.flavor == 2 && sb_takes) {
+                    if ((rc = ensure_packed_sb(u, cw))) return rc;
+                    {
                         const int TWs = op.narrow ? 8 : 16;
                         auto th_of = [&](int mt) { return op.narrow ? (mt == 2 ? 8 : 4) : (mt == 2 ? 4 : 2); };
                         auto sb_wgs = [&](int mt, int nt) { return (int64_t)((w + TWs - 1) / TWs) * ((h + th_of(mt) - 1) / th_of(mt)) * N * (cw.cout_pad / (32 * nt)); };
@@ -1113,16 +1125,17 @@ static int run_unet(td_unet* u, Plan& pl, int step, const SchedCoef* fuse = null
         hipError_t e = op.flavor == 4 ? launch_conv_sb(p, u->dt, op.narrow, op.sb_mt, op.sb_nt, st)
                        : op.flavor == 3 ? launch_conv_pp(p, u->dt, op.bn, u->eng->n_cus, st)
                        : op.flavor == 2 ? launch_conv_glds(p, u->dt, op.narrow, op.bn, op.glds_variant, st) : launch_conv(p, u->dt, op.narrow, op.bn, 0, st);
-        mark(); if (prof) { ev_kind.push_back(0); char tag[128]; double gf_ = 0.0; for (int si_ = 0; si_ < p.nseg; ++si_) gf_ += (double)p.seg[si_].C * p.seg[si_].taps; gf_ *= 2.0 * p.N * p.H * p.W * p.Cout * 1e-9;  /* algorithmic GFLOP of this launch */
+        mark(); if (prof) { ev_kind.push_back(0); char tag[160]; double gf_ = op.k_alg * 2.0 * p.N * p.H * p.W * p.Cout * 1e-9;  /* algorithmic GFLOP of this launch: REAL input channels (the 6-channel input conv is 5.4 GFLOP at batch 64, not the 58 its K padding to 64 would give) */
             /* algorithmic HBM megabytes of this launch: every source tensor once (at ITS resolution), the residual once, the outputs once, the weights once */
             double mb_ = 0.0; const double es_ = (double)u->esize();
             for (int si_ = 0; si_ < p.nseg; ++si_) mb_ += (double)p.N * p.seg[si_].Hs * p.seg[si_].Ws * p.seg[si_].C * es_ + (double)p.seg[si_].C / 64.0 * p.seg[si_].taps * p.CoutPad * 128.0 * (es_ / 2.0);
             if (p.res) mb_ += (double)p.N * p.res_Hs * p.res_Ws * p.Cout * es_;
-            mb_ += (double)p.N * p.H * p.W * p.Cout * (p.out_f32 ? 4.0 : es_) * (p.out2 ? 2.0 : 1.0);
+            const double o1_ = (double)p.N * p.H * p.W * p.Cout * (p.out_f32 ? 4.0 : es_);
+            const double mbs_ = (mb_ + o1_) * 1e-6;   /* strict: without the optional pre-activated second output (an optimisation, not part of the layer's definition) */
+            mb_ += o1_ * (p.out2 ? 2.0 : 1.0);
             mb_ *= 1e-6;
-            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f mb%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 4 ? (op.sb_mt == 2 ? (op.sb_nt == 2 ? "m2n2" : "m2n1") : (op.sb_nt == 2 ? "m1n2" : "m1n1")) : op.flavor == 3 ? "p" : op.flavor == 2 ? (op.glds_variant == 2 ? "t" : op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_, mb_); ev_label.push_back(op.label + tag);
-            double kk = 0; for (int s_ = 0; s_ < p.nseg; ++s_) kk += (double)p.seg[s_].C * p.seg[s_].taps;
-            ev_flop.push_back((op.flavor == 2 || op.flavor == 3) ? 2.0 * p.N * p.H * p.W * (double)p.Cout * kk : 0.0); }   // the LDS-DMA family alone (bench.py's roofline kernel); small-batch launches are told apart by their f4 label
+            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f mb%.2f mbs%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 4 ? (op.sb_mt == 2 ? (op.sb_nt == 2 ? "m2n2" : "m2n1") : (op.sb_nt == 2 ? "m1n2" : "m1n1")) : op.flavor == 3 ? "p" : op.flavor == 2 ? (op.glds_variant == 2 ? "t" : op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_, mb_, mbs_); ev_label.push_back(op.label + tag);
+            ev_flop.push_back((op.flavor == 2 || op.flavor == 3) ? 2.0 * p.N * p.H * p.W * (double)p.Cout * op.k_alg : 0.0); }   // the LDS-DMA family alone (bench.py's roofline kernel); small-batch launches are told apart by their f4 label
         if (e != hipSuccess) return fail(TD_ERR_HIP, "conv launch " + op.label + ": " + hipGetErrorString(e));
     }
     return TD_OK;
@@ -1179,8 +1192,22 @@ int td_engine_set_stream(td_engine* e, void* hip_stream) {
     e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
     return TD_OK;
 }
+// Every option the runtime reads.  td_engine_set_option refuses anything else: a misspelt key ("batch_invarient") used to be stored and never
+// read -- silently losing, e.g., the bit-identity of sharded runs.
+static const char* const kKnownOptions[] = {
+    // behaviour
+    "async", "batch_invariant", "fuse_solver", "graph", "lower_order_final", "profile", "solver_order", "dual_stream", "dual_stream_min_batch",
+    "plan_cache_mb", "plan_cache_max",
+    // plan builder (speed only, or test hooks that force a tile shape; all part of the plan-cache key)
+    "attn_mfma", "bn128_min_wgs", "glds", "glds_bn", "glds_bn64", "glds_dma1x1", "glds_min_wgs", "glds_round_aware", "glds_small_max_groups",
+    "glds_splitk", "glds_splitk_from_groups", "glds_splitk_max", "glds_splitk_min_groups", "glds_tiny", "glds_variant", "pp", "pp_min_items_per_cu",
+    "producer_act", "sb", "sb_max_glds_wgs", "sb_mt", "sb_nt", "sb_order", "sb_splitk", "sb_splitk_max", "sb_splitk_wgs", "sb_target_wgs", "splitk",
+    "splitk_target_wgs", "splitk_weighted", "walk_alternate"};
 int td_engine_set_option(td_engine* e, const char* key, int64_t value) {
     if (!e || !key) return fail(TD_ERR_ARG, "null");
+    bool known = false;
+    for (const char* k : kKnownOptions) known = known || strcmp(k, key) == 0;
+    if (!known) return fail(TD_ERR_ARG, std::string("unknown engine option \"") + key + "\" (include/td_engine.h lists the options)");
     e->opt[key] = value;
     return TD_OK;
 }

@@ -16,6 +16,12 @@ class Engine:
         self._h = C.c_void_p()
         check(lib().td_engine_create(int(device_id), C.byref(self._h)))
         self.device_id = int(device_id)
+        self._async = False
+
+    def set_async(self, on):
+        """option "async": calls on device tensors only enqueue (see on_stream)."""
+        self.set_option("async", 1 if on else 0)
+        self._async = bool(on)
 
     def set_option(self, key, value):
         check(lib().td_engine_set_option(self._h, key.encode(), int(value)))
@@ -67,18 +73,35 @@ class Engine:
 
         class _Ctx:
             def __enter__(self_):
-                self_.tctx = torch.cuda.stream(stream) if isinstance(stream, torch.cuda.Stream) else None
-                if self_.tctx is not None:
+                # re-entrant: remember what the engine ran on, and restore exactly that on exit (a sharded sampler called inside a caller's own
+                # on_stream block must not drop the caller's stream / enqueue-only mode for the rest of that block)
+                self_.prev_handle = _SHARED_STREAM.get(eng.device_id)
+                self_.prev_async = eng._async
+                self_.tctx = None
+                if isinstance(stream, torch.cuda.Stream):
+                    # torch side streams do not wait for the previously current stream: tensors produced there just before entry (conditioning
+                    # inputs, tiles cached by an earlier call) would be read on `stream` unordered, and ptr() no longer synchronises the host
+                    # once the engine shares torch's current stream
+                    stream.wait_stream(torch.cuda.current_stream(stream.device))
+                    self_.tctx = torch.cuda.stream(stream)
                     self_.tctx.__enter__()
-                eng.set_stream(stream)
-                eng.set_option("async", 1 if asynchronous else 0)
+                try:
+                    eng.set_stream(stream)
+                    eng.set_async(asynchronous)
+                except BaseException:
+                    if self_.tctx is not None:
+                        self_.tctx.__exit__(None, None, None)
+                    raise
                 return eng
 
             def __exit__(self_, *exc):
-                eng.set_option("async", 0)
-                eng.set_stream(None)     # drains the stream and releases the staging buffers
+                eng.set_async(False)
+                eng.set_stream(self_.prev_handle)     # drains the stream and releases the staging buffers
+                eng.set_async(self_.prev_async)
                 if self_.tctx is not None:
                     self_.tctx.__exit__(*exc)
+                    # whoever continues on the outer stream sees everything enqueued inside the block
+                    torch.cuda.current_stream(stream.device).wait_stream(stream)
                 return False
         return _Ctx()
 

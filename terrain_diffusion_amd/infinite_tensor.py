@@ -411,6 +411,39 @@ class DeviceWindowTensor(InfiniteTensor):
         check(lib().td_gather_regions(self.engine._h, self.channels, self.tile, n, h, w, maxk, _C.c_void_p(desc.ctypes.data), len(keep), _C.c_void_p(ptrs.ctypes.data), ptr(out)))
         return out
 
+    MAX_REGION_WINDOWS = 16
+
+    def _gather_cells(self, lo, hi):
+        """A large region as a grid of cells cut at multiples of 3 window strides (<= (3 + ceil(tile / stride) - 1)^2 windows touch a cell): the
+        cells of one size are one gather_many call and one strided copy (<= 9 size classes: interior, four edges, four corners).  Per pixel the
+        same windows are summed in the same ascending (row, col) order as in the one-region path -- bit-identical, but O(cell windows) per pixel."""
+        C1 = self.channels + 1
+        step = 3 * self.stride_hw
+        self._ensure(sorted(self._windows_for([0, lo[1], lo[2]], [C1, hi[1], hi[2]])))   # missing windows of the WHOLE region in as few batches as allowed
+
+        def cuts(l, h, o):
+            first = ((l - o) // step + 1) * step + o
+            return [l] + list(range(first, h, step)) + [h]
+        ys, xs = cuts(lo[1], hi[1], self.output_window.offset[1]), cuts(lo[2], hi[2], self.output_window.offset[2])
+        out = torch.empty((C1, hi[1] - lo[1], hi[2] - lo[2]), dtype=torch.float32, device=self.device)
+
+        def classes(c):   # runs of consecutive equal-sized intervals: [(first index, count, size)]
+            runs = []
+            for k in range(len(c) - 1):
+                sz = c[k + 1] - c[k]
+                if runs and runs[-1][2] == sz:
+                    runs[-1][1] += 1
+                else:
+                    runs.append([k, 1, sz])
+            return runs
+        for ky, ny, h in classes(ys):
+            for kx, nx, w in classes(xs):
+                bounds = [((0, C1), (ys[ky + a], ys[ky + a] + h), (xs[kx + b], xs[kx + b] + w)) for a in range(ny) for b in range(nx)]
+                res = self.gather_many(bounds)   # (ny * nx, C1, h, w)
+                y0, x0 = ys[ky] - lo[1], xs[kx] - lo[2]
+                out[:, y0:y0 + ny * h, x0:x0 + nx * w] = res.view(ny, nx, C1, h, w).permute(2, 0, 3, 1, 4).reshape(C1, ny * h, nx * w)
+        return out
+
     def __getitem__(self, idx):
         lo, hi, squeeze = self._normalize_slices(idx)
         if any(h <= l for l, h in zip(lo, hi)):   # empty region: nothing to evaluate
@@ -425,8 +458,14 @@ class DeviceWindowTensor(InfiniteTensor):
                 sub = sub.squeeze(d)
             return sub
         # one region = a batch of one for the region-gather kernel (same per-pixel window order and arithmetic as td_blend_windows; no descriptor
-        # tables to build and upload per call, and nothing that ends the call with a host synchronisation when the engine runs enqueue-only)
-        canvas = self.gather_many([((0, self.channels + 1), (lo[1], hi[1]), (lo[2], hi[2]))])[0]
+        # tables to build and upload per call, and nothing that ends the call with a host synchronisation when the engine runs enqueue-only).
+        # The kernel visits, per pixel, every window listed for its region: a region that many windows touch (a large world.get box) is therefore
+        # cut along the window grid into cells that <= MAX_REGION_WINDOWS windows touch each (_gather_cells)
+        n_win = len(self._windows_for([0, lo[1], lo[2]], [self.channels + 1, hi[1], hi[2]]))
+        if n_win > self.MAX_REGION_WINDOWS:
+            canvas = self._gather_cells(lo, hi)
+        else:
+            canvas = self.gather_many([((0, self.channels + 1), (lo[1], hi[1]), (lo[2], hi[2]))])[0]
         for d in reversed([d for d in squeeze if d != 0]):
             canvas = canvas.squeeze(d)
         return canvas

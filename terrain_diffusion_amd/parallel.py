@@ -142,6 +142,9 @@ def _engine_stream(model):
     if dev.type != "cuda":
         return contextlib.nullcontext()
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    from .engine import engine_on_current_stream
+    if engine_on_current_stream(dev):
+        return contextlib.nullcontext()   # the caller already put the engine on torch's current stream (Engine.on_stream): keep it, and its mode
     if idx not in _EXCHANGE_STREAMS:
         _EXCHANGE_STREAMS[idx] = torch.cuda.Stream(device=idx)
     return model.engine.on_stream(_EXCHANGE_STREAMS[idx], asynchronous=False)
@@ -184,20 +187,17 @@ def engine_fns(model, scheduler, plan, cond_inputs, *, cond_means, cond_stds, no
 
 def sample_base_diffusion_sharded(model, scheduler, shape, cond_inputs, *, cond_means, cond_stds, noise_level=0.0, histogram_raw, steps=15,
                                   tile_size=64, noise_seed=42 + 5819, noise_origin=(0, 0), max_batch=64, group=None, gather_to=None,
-                                  sample_fn=None, blend_fn=None, normalize_fn=None, stats=None):
+                                  sample_fn=None, blend_fn=None, normalize_fn=None, stats=None, _on_engine_stream=False):
     """Sharded sample_base_diffusion (terrain_diffusion/training/evaluation/sample_diffusion_base.py:115-168).
     Returns (region_tensor (C,h,w), (y0,y1,x0,x1)) for this rank, or the assembled (1,C,H,W) on rank `gather_to`.
     sample_fn / blend_fn / normalize_fn default to the HIP engine; tests inject CPU stand-ins to exercise the plumbing under gloo."""
-    if sample_fn is None and model is not None and not getattr(_engine_stream, "_inside", False):
-        # engine path: everything below runs on the engine's side stream (see _engine_stream)
+    if sample_fn is None and model is not None and not _on_engine_stream:
+        # engine path: everything below runs on the engine's side stream (see _engine_stream); the flag travels as an argument, not as global
+        # state, so concurrent callers (threads, devices) cannot see each other's
         with _engine_stream(model):
-            _engine_stream._inside = True
-            try:
-                return sample_base_diffusion_sharded(model, scheduler, shape, cond_inputs, cond_means=cond_means, cond_stds=cond_stds, noise_level=noise_level,
-                                                     histogram_raw=histogram_raw, steps=steps, tile_size=tile_size, noise_seed=noise_seed, noise_origin=noise_origin,
-                                                     max_batch=max_batch, group=group, gather_to=gather_to, stats=stats)
-            finally:
-                _engine_stream._inside = False
+            return sample_base_diffusion_sharded(model, scheduler, shape, cond_inputs, cond_means=cond_means, cond_stds=cond_stds, noise_level=noise_level,
+                                                 histogram_raw=histogram_raw, steps=steps, tile_size=tile_size, noise_seed=noise_seed, noise_origin=noise_origin,
+                                                 max_batch=max_batch, group=group, gather_to=gather_to, stats=stats, _on_engine_stream=True)
     B, C_, H, W = shape
     assert B == 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -279,7 +279,7 @@ def consistency_engine_fns(model, plan, cond_inputs, *, cond_means, cond_stds, n
 
 def sample_base_consistency_sharded(model, scheduler, shape, cond_inputs, *, cond_means, cond_stds, noise_level=0.0, histogram_raw, intermediate_t=0.0,
                                     tile_size=64, noise_seed=42 + 5819, noise_origin=(0, 0), max_batch=64, group=None, gather_to=None,
-                                    step_fn=None, blend_fn=None, normalize_fn=None, stats=None):
+                                    step_fn=None, blend_fn=None, normalize_fn=None, stats=None, _on_engine_stream=False):
     """Sharded sample_base_consistency (sample_diffusion_base.py:171-268; the latent stage's blended trig-flow phases, world_pipeline.py:1133-1203).
     T phases = T seam exchanges: in every phase a rank runs one consistency step on ITS windows, then receives the outputs of the
     neighbours' windows it needs and blends
@@ -287,15 +287,12 @@ def sample_base_consistency_sharded(model, scheduler, shape, cond_inputs, *, con
         sample out of that box, so no blended canvas ever crosses a seam, only window outputs do (canonical per-pixel summation order);
       * after the last phase: the region it owns.
     In batch-invariant engine mode the assembled canvas is bit-identical to the one-rank sampler.  Returns like sample_base_diffusion_sharded."""
-    if step_fn is None and model is not None and not getattr(_engine_stream, "_inside", False):
+    if step_fn is None and model is not None and not _on_engine_stream:
         with _engine_stream(model):   # engine path: sample -> exchange -> blend of every phase on the engine's side stream
-            _engine_stream._inside = True
-            try:
-                return sample_base_consistency_sharded(model, scheduler, shape, cond_inputs, cond_means=cond_means, cond_stds=cond_stds, noise_level=noise_level,
-                                                       histogram_raw=histogram_raw, intermediate_t=intermediate_t, tile_size=tile_size, noise_seed=noise_seed,
-                                                       noise_origin=noise_origin, max_batch=max_batch, group=group, gather_to=gather_to, stats=stats)
-            finally:
-                _engine_stream._inside = False
+            return sample_base_consistency_sharded(model, scheduler, shape, cond_inputs, cond_means=cond_means, cond_stds=cond_stds, noise_level=noise_level,
+                                                   histogram_raw=histogram_raw, intermediate_t=intermediate_t, tile_size=tile_size, noise_seed=noise_seed,
+                                                   noise_origin=noise_origin, max_batch=max_batch, group=group, gather_to=gather_to, stats=stats,
+                                                   _on_engine_stream=True)
     B, C_, H, W = shape
     assert B == 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
