@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--region", type=int, default=0, help="cascade workload: side of the decoded region per step in pixels (default 3072 at N=1, 6144 at N>1)")
     ap.add_argument("--cascade-sync", type=int, default=0, help="cascade workload: 1 = every engine call synchronous (complete on return) instead of enqueue-only on one stream")
     ap.add_argument("--cache-mib", type=int, default=100, help="cascade workload: window-cache cap in MiB (default = the reference's cache_limit)")
-    ap.add_argument("--engine-opts", default="", help="engine options for A/B runs, e.g. dual_stream=0,pp=1 (recorded in config.engine_opts)")
+    ap.add_argument("--engine-opts", default="", help="engine options for A/B runs, e.g. dual_stream=1,s16=0 (recorded in config.engine_opts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-tile latency leg (keeps rocprofv3 counter passes to the batched steps only)")
@@ -215,7 +215,7 @@ def main():
             one_step(10_000)
             sync()
             g_ms, g_flop, g_n = eng.profile_read_glds(reset=True)
-            sb_rows = [(float(re.search(r" gf([0-9.]+)", l_).group(1)), ms_, n_) for l_, ms_, n_ in eng.profile_ops() if re.search(r" f4\w* bn", l_)]
+            sb_rows = [(float(re.search(r" gf([0-9.]+)", l_).group(1)), ms_, n_) for l_, ms_, n_ in eng.profile_ops() if re.search(r" f[45]\w* bn", l_)]
             conv_ms, conv_n, other_ms, other_n = eng.profile_read(reset=True)
             eng.set_option("profile", 0)
             roof.update({"all_conv_kernels_ms_per_step": round(conv_ms, 3), "all_conv_launches_per_step": conv_n,
@@ -224,7 +224,7 @@ def main():
                 sb_ms = sum(ms_ for _, ms_, _ in sb_rows); sb_gf = sum(gf_ * n_ for gf_, _, n_ in sb_rows)
                 roof["small_batch_kernel"] = {"kernel": "td::conv_sb_kernel", "launches_per_step": sum(n_ for _, _, n_ in sb_rows), "kernel_ms_per_step": round(sb_ms, 3),
                                               "achieved": round(sb_gf / sb_ms, 2) if sb_ms > 0 else None, "unit": "TFLOP/s"}
-            if g_n > 0:   # dominant kernel family: the LDS-DMA implicit-GEMM conv (terrain_diffusion_amd/csrc/conv_glds.hip / conv_pp.hip)
+            if g_n > 0:   # dominant kernel family: the LDS-DMA implicit-GEMM conv (terrain_diffusion_amd/csrc/conv_glds.hip)
                 ach = g_flop / (g_ms * 1e-3) / 1e12
                 dual_on = "dual_stream=1" in args.engine_opts or (strong and "dual_stream=0" not in args.engine_opts)
                 lanes = 2 if (dual_on and min(tiles_per_step, 64) >= 32) else 1
@@ -264,7 +264,7 @@ def main():
                                                 f"{bid}: stale counters are not reported (re-run tools/collect_profiles.sh)")
                     else:
                         tj = pj["kernels"]
-                        ks_ = [v for k_, v in tj.items() if ("conv_glds_kernel" in k_ or "conv_pp_kernel" in k_) and v.get("dispatches") and "hbm_read_bytes_per_launch" in v]
+                        ks_ = [v for k_, v in tj.items() if "conv_glds_kernel" in k_ and v.get("dispatches") and "hbm_read_bytes_per_launch" in v]
                         n_ = sum(v["dispatches"] for v in ks_)
                         if n_:
                             roof["traffic"] = round(sum(v["dispatches"] * (v["hbm_read_bytes_per_launch"] + v.get("hbm_write_bytes_per_launch", 0)) for v in ks_) / n_)

@@ -1,4 +1,4 @@
-// Device helpers shared by the three conv flavours (conv_igemm.hip, conv_glds.hip, conv_pp.hip): element types, the fused
+// Device helpers shared by the conv flavours (conv_igemm.hip, conv_glds.hip, conv_sb.hip, conv_s16.hip): element types, the fused
 // prologue / epilogue arithmetic, the LDS swizzle and lane->pixel maps, the LDS-DMA statement.  gfx950 only.
 #pragma once
 #include "td_device.h"
@@ -207,6 +207,15 @@ __device__ __forceinline__ float pixel_rn(const float* sumsq, int nparts, size_t
     float s = 0.f;
     const float* b = sumsq + sp;
     int q = 0;
+    // (round 5: sixteen at a time first -- ops on the 64 px x 16 cout flavour keep one plane per 16 couts, 36-48 planes at the deep levels, and every
+    // round of this loop is one memory round trip in front of the consumer's first restage; the ascending order of the additions is unchanged)
+    for (; q + 16 <= nparts; q += 16) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = b[(size_t)(q + u) * npix];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += t[u];
+    }
     for (; q + 8 <= nparts; q += 8) {
         float t[8];
 #pragma unroll
@@ -249,7 +258,7 @@ __device__ __forceinline__ void swap_halves(unsigned& a, unsigned& b) {
     a = r[0]; b = r[1];
 }
 
-// One unit of the wide 16-bit epilogue (conv_glds.hip, conv_pp.hip): 8 accumulators of ONE pixel -- MFMA row groups 2m and 2m+1 of a 32x32
+// One unit of the wide 16-bit epilogue (conv_glds.hip, conv_sb.hip): 8 accumulators of ONE pixel -- MFMA row groups 2m and 2m+1 of a 32x32
 // block, i.e. couts c..c+3 (va) and c+8..c+11 (vb) on this lane, its partner lane l^32 holding c+4.. and c+12.. -- are transformed, rounded to
 // T, and lane-pair transposed (v_permlane32_swap) into one 16-byte run per lane: o = 8 consecutive couts of the output, o2 = the consumer's
 // mp_silu(scale * x) of the ROUNDED values (what its patch staging would compute), ss += sum of squares of the rounded values (pairwise

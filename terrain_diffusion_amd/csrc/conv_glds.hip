@@ -57,8 +57,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, TD_GLDS_MIN_WAVES(BN, WAVES
     constexpr int A_BASE = RING * B_BYTES, A_BYTES = NPATCH * PITCH;
     // round 5: the modulation rows c[n][co0 .. co0 + BN) of the tile's images (EPI_EMB_SILU) are staged in LDS by the prologue -- the epilogue then
     // reads them with ds_read_b128 instead of 2 x NT x 2 global loads per pixel row group between the last MFMA and the first store.  Behind
-    // everything else (patch + 1/rms table, or the 1x1 stage buffers of the DMA instantiation).
-    constexpr int CV_BASE = A_BASE + ((A_BYTES + NPATCH * 4 > (DMA1 ? NST * STAGE_BYTES : 0) ? A_BYTES + NPATCH * 4 : NST * STAGE_BYTES) + 15) / 16 * 16;
+    // the patch and the 1/rms table.
+    constexpr int CV_BASE = A_BASE + (A_BYTES + NPATCH * 4 + 15) / 16 * 16;   // (plain instantiation only)
     constexpr int NU = NT * 2;   // epilogue units (8 couts of one pixel) per 32-pixel row group
     static_assert(NIMG * BN <= NTHR, "modulation rows: one element per thread");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "tile shape");
@@ -135,6 +135,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, TD_GLDS_MIN_WAVES(BN, WAVES
     }
     TD_GLDS_B(0);
     TD_GLDS_B(1);
+    // modulation rows of this tile (EPI_EMB_SILU; zero where there is no image / no cout): requested here, written to LDS in front of the prologue's
+    // barrier.  Never in the DMA instantiation: launch_glds_cfg keeps EPI_EMB_SILU launches on the plain one, and 512 more bytes of LDS would cost
+    // the bn 128 DMA tile -- 48 KB ring + 32 KB of stage buffers = exactly half a CU's LDS -- its second workgroup per CU.
+    const bool cv_stage = !DMA1 && k_epi == EPI_EMB_SILU && tid < NIMG * BN;
+    float cv_val = 0.f;
+    if (cv_stage) {
+        const int im = tid / BN, c = tid - im * BN;
+        if (n0 + im < k_N && co0 + c < k_Cout) cv_val = p.cvec[(size_t)(n0 + im) * k_cvs + co0 + c];
+    }
 
     // ---- activation-patch staging.  Per thread A_ITERS 16-byte pieces (patch pixel e>>3, slot e&7).  The packed coordinate is
     // segment independent; the element offset of the piece inside a segment's source tensor (aoff) is recomputed once per SEGMENT,
@@ -239,11 +248,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, TD_GLDS_MIN_WAVES(BN, WAVES
         }
     }
 
-    if (k_epi == EPI_EMB_SILU && tid < NIMG * BN) {   // modulation rows of this tile (zero where there is no image / no cout)
-        const int im = tid / BN, c = tid - im * BN;
-        const bool v = n0 + im < k_N && co0 + c < k_Cout;
-        s_cv[tid] = v ? p.cvec[(size_t)(n0 + im) * k_cvs + co0 + c] : 0.f;
-    }
+    if (cv_stage) s_cv[tid] = cv_val;   // (requested at the top of the prologue)
 
     // ---- MFMA operand addressing: weights = A operand (rows = couts), activations = B operand (cols = pixels).
     // xbase: LDS byte address of the TOP-LEFT tap of this lane's pixel (+ its k-half); a tap adds ((dy*PW + dx) * PITCH), a 16-deep
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, TD_GLDS_MIN_WAVES(BN, WAVES
         const int n = n0 + img, y = y0 + ty, x = x0 + tx;
         const bool ok = n < k_N && y < k_H && x < k_W;
         // sums of squares (pixel-norm statistic of the consumer) are kept per 32-cout MFMA block: the partial decomposition -- and with it
-        // the fp32 summation order the consumer sees -- is then the same for every tile shape (bn 96 / 128, 4 or 8 waves, ping-pong)
+        // the fp32 summation order the consumer sees -- is then the same for every tile shape (bn 96 / 128, 4 or 8 waves)
         float ssj[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) ssj[j] = 0.f;
@@ -617,7 +622,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, TD_GLDS_MIN_WAVES(BN, WAVES
                         if (want_o2) *(u32x4*)((T*)p.out2 + (orow - (T*)p.out) + j * 32 + m * 16) = o2;
                     }
                 };
-                if (e_epi == EPI_EMB_SILU) body(std::integral_constant<int, 1>{});
+                if (e_epi == EPI_EMB_SILU) { if constexpr (!DMA1) body(std::integral_constant<int, 1>{}); }
                 else if (has_res) body(std::integral_constant<int, 2>{});
                 else body(std::integral_constant<int, 0>{});
             } else {
@@ -681,7 +686,8 @@ static hipError_t launch_glds_cfg(const ConvParams& p, hipStream_t st) {
     for (int s = 0; s < p.nseg && dma; ++s) if (p.seg[s].taps != 9 && p.seg[s].xform != 0) dma = false;
     const int grid = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * p.ksplit;
     constexpr bool HAS_DMA = true;
-    const size_t lds = RING_BYTES + ((dma ? std::max(PATCH_RN, STAGES) : PATCH_RN) + 15) / 16 * 16 + CV_BYTES + (size_t)g_bench_extra_lds;
+    if (p.epi == EPI_EMB_SILU) dma = false;   // the modulation rows live in LDS behind the patch: the plain instantiation only (no such launch has 1x1 segments in the U-Net)
+    const size_t lds = RING_BYTES + (dma ? std::max(PATCH_RN, STAGES) : (PATCH_RN + 15) / 16 * 16 + CV_BYTES) + (size_t)g_bench_extra_lds;
     pd.dma1x1 = dma ? 1 : 0;
     {   // workgroup-id decode constants of the kernel prologue
         const int mtiles_ = p.tiles_x * p.tiles_y * p.img_groups;

@@ -214,6 +214,13 @@ __global__ __launch_bounds__(256, 2) void conv_sb_kernel(const ConvParams p) {
                 const float* sp = rn_sumsq + sb_src_pixel(n0, y, x, rn_Hs, rn_Ws, rn_res == 1, rn_res == 2);
                 float s = 0.f;
                 int q = 0;
+                for (; q + 16 <= rn_parts; q += 16) {   // (sixteen at a time first: pixel_rn of conv_common.h says why)
+                    float t[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) t[u] = sp[(size_t)(q + u) * npix];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) s += t[u];
+                }
                 for (; q + 8 <= rn_parts; q += 8) {
                     float t[8];
 #pragma unroll

@@ -17,8 +17,8 @@
 // single translation unit: kernels are compiled together with the host runtime
 #include "conv_igemm.hip"
 #include "conv_glds.hip"
-#include "conv_pp.hip"
 #include "conv_sb.hip"
+#include "conv_s16.hip"
 #include "small_kernels.hip"
 #include "compose_kernels.hip"
 #include "attn_mfma.hip"
@@ -160,7 +160,7 @@ struct td_engine {
     bool call_host_src = false;   // this call copied from a caller-owned host array that could not be staged: it must end synchronously
     int device = 0;
     int n_cus = 256;
-    void* zeros = nullptr;     // 4 KiB of zeros: halo source of the LDS-DMA patch staging (conv_pp.hip)
+    void* zeros = nullptr;     // 4 KiB of zeros: a readable page of zeros for the kernels (ConvParams::zeros)
     hipStream_t stream = nullptr;   // the stream every call enqueues on: the engine's own, or the caller's (td_engine_set_stream)
     hipStream_t own_stream = nullptr;
     hipStream_t stream2 = nullptr;  // second lane of the batched EDM sampler (sample_edm_impl): two half-batches run concurrently
@@ -273,6 +273,7 @@ struct ConvWeights {
     Buf packed_sb;             // 16-bit modes: the same weights in MFMA-fragment order for the small-batch flavour (conv_sb.hip); made the first
                                // time a plan puts this op on that flavour (ensure_packed_sb): never with option "sb" = 0 / "batch_invariant" = 1
     size_t packed_bytes = 0;   // bytes of weights in `packed` (without its tail padding)
+    Buf packed_s16;            // the fragment order of the deep-level latency flavour (conv_s16.hip), likewise made on first use
     int sb_n3 = 0, sb_g1 = 0;  // its leading 3x3 K-groups / trailing 1x1 K-groups (sb_n3 < 0: segment order not supported by that flavour)
 };
 
@@ -290,7 +291,8 @@ struct Op {
     int bn = 64;
     int glds_variant = 0;      // 0: 8 waves x 256 pixels, 1: 4 waves x 128 pixels
     int flavor = 0;            // 0: per-tap register-staged kernel (conv_igemm.hip); 2: LDS-DMA throughput kernel (conv_glds.hip);
-                               // 3: persistent ping-pong kernel (conv_pp.hip); 4: small-batch kernel, K split over the waves of a workgroup (conv_sb.hip)
+                               // (3 was the persistent ping-pong kernel of rounds 2-4, removed in round 5); 4: small-batch kernel, K split over the waves of a workgroup (conv_sb.hip);
+                               // 5: deep-level latency kernel, 64 px x 16 couts on 16x16x32 MFMAs (conv_s16.hip)
     int sb_mt = 2, sb_nt = 2;  // flavour 4: 32-pixel / 32-cout MFMA blocks per workgroup
     int cvec_off = -1;         // EPI_EMB_SILU: offset of this block's c vector
     double k_alg = 0.0;        // sum over the K-segments of (real input channels x taps): the algorithmic K of the op (profile labels, roofline FLOP)
@@ -330,7 +332,7 @@ struct Plan {
 struct td_unet {
     td_engine* eng = nullptr;
     td_unet_config cfg;
-    bool bf16 = false;         // 16-bit storage (bf16 OR fp16): 64-channel K chunks, LDS-DMA / ping-pong conv flavours available
+    bool bf16 = false;         // 16-bit storage (bf16 OR fp16): 64-channel K chunks, LDS-DMA / small-batch conv flavours available
     int dt = TD_DTYPE_F32;     // TD_DTYPE_*
     int chunk = 32;            // channels per 128-byte K chunk
     int emb_ch = 0, noise_dims = 0, c_total = 0;
@@ -514,6 +516,14 @@ static int ensure_packed_sb(td_unet* u, ConvWeights& cw) {
     return TD_OK;
 }
 
+static int ensure_packed_s16(td_unet* u, ConvWeights& cw) {
+    if (cw.packed_s16 || cw.sb_n3 < 0) return TD_OK;
+    cw.packed_s16.reset(new DevBuf());
+    HIP_TRY(cw.packed_s16->alloc(cw.packed_bytes + 16384, true));
+    HIP_TRY(launch_s16_repack(cw.packed->p, cw.packed_s16->p, cw.cout_pad, cw.sb_n3, cw.sb_g1, u->eng->stream));
+    return TD_OK;
+}
+
 static const float kMixRes = 0.7f / 0.76157731058639082f;   // (1-0.3)/sqrt(0.7^2+0.3^2)
 static const float kMixNew = 0.3f / 0.76157731058639082f;
 
@@ -651,10 +661,10 @@ struct SegSpec { const Tensor* t; int C; int taps; int resample; int xform; floa
 
 static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0) {
     // every option the plan builder reads is part of the cache key (a plan built under other options must never be reused)
-    static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn", "pp",
-                                               "pp_min_items_per_cu", "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
+    static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn",
+                                               "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
                                                "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups", "glds_round_aware", "walk_alternate", "glds_tiny", "glds_dma1x1", "splitk_weighted",
-                                               "sb", "sb_target_wgs", "sb_mt", "sb_nt", "sb_order", "sb_max_glds_wgs", "sb_splitk", "sb_splitk_wgs", "sb_splitk_max"};
+                                               "sb", "sb_target_wgs", "sb_mt", "sb_nt", "sb_order", "sb_max_glds_wgs", "sb_splitk", "sb_splitk_wgs", "sb_splitk_max", "s16", "s16_min_wgs"};
     std::string key = std::to_string(N) + "_" + std::to_string(H) + "_" + std::to_string(W);
     for (const char* o : kPlanOptions) key += "_" + std::to_string((long long)u->eng->option(o, -7));
     if (lane) key += "_lane" + std::to_string(lane);   // a second, independent activation set of the same shape (concurrent half-batches)
@@ -799,17 +809,6 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                         p.ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(kgroups, u->eng->option("glds_splitk_max", 32)), 384 / wgs_tiny));
                     }
                 }
-                // persistent ping-pong flavour (conv_pp.hip): 3x3-only convs on >= 16-wide maps whose work items fill the chip at least
-                // "pp_min_items_per_cu" times; bit-identical to the LDS-DMA flavour (same K order, same MFMA), so the choice may depend on the batch
-                bool all9 = true;
-                for (int i = 0; i < p.nseg; ++i) all9 = all9 && p.seg[i].taps == 9;
-                const int64_t pp_items = tiles(16, 1) * (cw.cout_pad / bn2);
-                const int64_t pp_mode = u->eng->option("pp", 0);  // 0 off (default: measured on par with the LDS-DMA flavour), 1 auto, 2 wherever legal
-                if (pp_mode && bn2 != 64 && all9 && !op.narrow && !out_f32 && cw.cout % 8 == 0 && p.ksplit == 1 &&
-                    (pp_mode == 2 || pp_items >= u->eng->option("pp_min_items_per_cu", 2) * (int64_t)u->eng->n_cus)) {
-                    op.flavor = 3; op.glds_variant = 0;
-                    p.tiles_x = (w + 15) / 16; p.tiles_y = (h + 15) / 16; p.img_groups = N;
-                }
                 // Small-batch flavour (conv_sb.hip, round 4) wherever the throughput tiles do not fill the chip (workgroups x 2 <= CU slots: the
                 // launches that used to split K over WORKGROUPS).  K is split over the four waves of a workgroup and reduced through LDS: no fp32
                 // partial planes in HBM, no reduce launch (BASELINE configs[1]: one tile x 20 steps; the 1-16-window batches of the cascade's latent
@@ -819,7 +818,6 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                 // and the reduce launch costs less than the weight stream gains (tools/sb_splitk.sh: 8x8 1536->768 39 -> 17 us cold).
                 // Not in batch_invariant mode (conv_glds stays pinned): the K order differs, so the choice must not depend on the batch.
                 if (op.flavor == 2 && sb_takes) {
-                    if ((rc = ensure_packed_sb(u, cw))) return rc;
                     {
                         const int TWs = op.narrow ? 8 : 16;
                         auto th_of = [&](int mt) { return op.narrow ? (mt == 2 ? 8 : 4) : (mt == 2 ? 4 : 2); };
@@ -834,9 +832,27 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                         const int64_t fmt = u->eng->option("sb_mt", 0), fnt = u->eng->option("sb_nt", 0);   // test hooks
                         if (fmt == 1 || fmt == 2) { mt = (int)fmt; ks = 1; }
                         if (fnt == 1 || fnt == 2) { nt = (int)fnt; ks = 1; }
+                        // Round 5: the launches that would split K over workgroups on top (the weight-streaming-bound 8x8 / 16x16 levels of one or
+                        // two tiles) take the deep-level latency flavour instead (conv_s16.hip: 64 px x 16 couts, twice the workgroups per weight
+                        // byte, no partial planes, no reduce launch).  Option "s16": 1 = there (default), 0 = never, 2 = wherever conv_sb applies (test hook).
+                        const int64_t s16_mode = u->eng->option("s16", 1);
+                        // Measured (profiles/r05_conv_s16_deep_levels.txt): it wins where its own grid reaches about half the chip (16x16 level of one tile:
+                        // 144 workgroups, 8.9 against 10.1 us for 576 -> 576) and loses where it does not (8x8 level: 48 workgroups each streaming
+                        // 16 x K weights with 36 KB in flight per CU: 12.1 against 9.0 us) -- there split-K over workgroups stays.
+                        const int64_t wgs16 = sb_wgs(2, 1) * 2;
+                        const bool s16 = s16_mode == 2 || (s16_mode == 1 && fmt == 0 && fnt == 0 && sb_wgs(2, 2) < target && sb_wgs(2, 1) < target &&
+                                                           wgs16 <= u->eng->option("sb_splitk_wgs", 224) && wgs16 >= u->eng->option("s16_min_wgs", 128));
+                        if (s16) {
+                            if ((rc = ensure_packed_s16(u, cw))) return rc;
+                            op.flavor = 5; op.sb_mt = 2; op.sb_nt = 0; p.ksplit = 1;
+                            p.tiles_x = (w + TWs - 1) / TWs; p.tiles_y = (h + th_of(2) - 1) / th_of(2); p.img_groups = N; p.n_ntiles = cw.cout_pad / 16;
+                            p.wpack_sb = cw.packed_s16->p; p.sb_n3 = cw.sb_n3;
+                        } else {
+                        if ((rc = ensure_packed_sb(u, cw))) return rc;
                         op.flavor = 4; op.sb_mt = mt; op.sb_nt = nt; p.ksplit = ks < 1 ? 1 : ks;
                         p.tiles_x = (w + TWs - 1) / TWs; p.tiles_y = (h + th_of(mt) - 1) / th_of(mt); p.img_groups = N; p.n_ntiles = cw.cout_pad / (32 * nt);
                         p.wpack_sb = cw.packed_sb->p; p.sb_n3 = cw.sb_n3;
+                        }
                         // workgroup order (speed only): the operand that is larger decides which siblings share an XCD's L2.  Weights (every layer
                         // of a single tile: 0.2 - 21 MB against <= 4.7 MB of activations): the pixel tiles of a cout tile are adjacent, so an XCD
                         // fetches few cout tiles' weights instead of all of them (batch 1: 1636 -> 1121 MB fetched per forward, tools/r04_order.sh);
@@ -872,9 +888,9 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
         if (p.ksplit > 64) p.ksplit = 64;
         if (!conv_set_kbounds(p, u->eng->option("splitk_weighted", 1) != 0, chunk)) return fail(TD_ERR_UNSUPPORTED, "split-K bounds: " + label);
         p.epi = epi; p.out_f32 = out_f32 ? 1 : 0; p.clip = clip; p.zeros = u->eng->zeros;
-        // pixel-norm partials of the output: LDS-DMA / ping-pong flavours write one per 32-cout MFMA block (independent of the tile shape),
+        // pixel-norm partials of the output: the LDS-DMA and small-batch flavours write one per 32-cout MFMA block, the 64 x 16 flavour one per 16 couts (independent of the tile shape),
         // the per-tap flavour one per (cout tile, wave column), the split-K reduce kernel one per 256 couts
-        const int out_parts = p.ksplit > 1 ? (cw.cout_pad + 255) / 256 : (op.flavor >= 2 ? cw.cout_pad / 32 : p.n_ntiles * 2);
+        const int out_parts = p.ksplit > 1 ? (cw.cout_pad + 255) / 256 : op.flavor == 5 ? cw.cout_pad / 16 : (op.flavor >= 2 ? cw.cout_pad / 32 : p.n_ntiles * 2);
         if (out_f32) {
             outT->C = cw.cout; outT->cstride = 8; outT->H = h; outT->W = w; outT->sumsq = nullptr;
             if ((rc = new_buf(pl, (size_t)N * h * w * 8 * 4, &outT->ptr))) return rc;
@@ -1122,8 +1138,8 @@ static int run_unet(td_unet* u, Plan& pl, int step, const SchedCoef* fuse = null
             p.epi = EPI_DPM_STEP; p.dpm_x = (float*)pl.x->p; p.dpm_m1 = (float*)pl.m1->p; p.dpm_m2 = u->eng->option("solver_order", 2) == 3 ? (float*)pl.m2->p : nullptr; p.dpm_xin = pl.xin; p.dpm_xin_cstride = u->chunk; p.dpm_k = *fuse;
         }
         mark();
-        hipError_t e = op.flavor == 4 ? launch_conv_sb(p, u->dt, op.narrow, op.sb_mt, op.sb_nt, st)
-                       : op.flavor == 3 ? launch_conv_pp(p, u->dt, op.bn, u->eng->n_cus, st)
+        hipError_t e = op.flavor == 5 ? launch_conv_s16(p, u->dt, op.narrow, st)
+                       : op.flavor == 4 ? launch_conv_sb(p, u->dt, op.narrow, op.sb_mt, op.sb_nt, st)
                        : op.flavor == 2 ? launch_conv_glds(p, u->dt, op.narrow, op.bn, op.glds_variant, st) : launch_conv(p, u->dt, op.narrow, op.bn, 0, st);
         mark(); if (prof) { ev_kind.push_back(0); char tag[160]; double gf_ = op.k_alg * 2.0 * p.N * p.H * p.W * p.Cout * 1e-9;  /* algorithmic GFLOP of this launch: REAL input channels (the 6-channel input conv is 5.4 GFLOP at batch 64, not the 58 its K padding to 64 would give) */
             /* algorithmic HBM megabytes of this launch: every source tensor once (at ITS resolution), the residual once, the outputs once, the weights once */
@@ -1134,8 +1150,8 @@ static int run_unet(td_unet* u, Plan& pl, int step, const SchedCoef* fuse = null
             const double mbs_ = (mb_ + o1_) * 1e-6;   /* strict: without the optional pre-activated second output (an optimisation, not part of the layer's definition) */
             mb_ += o1_ * (p.out2 ? 2.0 : 1.0);
             mb_ *= 1e-6;
-            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f mb%.2f mbs%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 4 ? (op.sb_mt == 2 ? (op.sb_nt == 2 ? "m2n2" : "m2n1") : (op.sb_nt == 2 ? "m1n2" : "m1n1")) : op.flavor == 3 ? "p" : op.flavor == 2 ? (op.glds_variant == 2 ? "t" : op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_, mb_, mbs_); ev_label.push_back(op.label + tag);
-            ev_flop.push_back((op.flavor == 2 || op.flavor == 3) ? 2.0 * p.N * p.H * p.W * (double)p.Cout * op.k_alg : 0.0); }   // the LDS-DMA family alone (bench.py's roofline kernel); small-batch launches are told apart by their f4 label
+            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f mb%.2f mbs%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 5 ? "c16" : op.flavor == 4 ? (op.sb_mt == 2 ? (op.sb_nt == 2 ? "m2n2" : "m2n1") : (op.sb_nt == 2 ? "m1n2" : "m1n1")) : op.flavor == 2 ? (op.glds_variant == 2 ? "t" : op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_, mb_, mbs_); ev_label.push_back(op.label + tag);
+            ev_flop.push_back(op.flavor == 2 ? 2.0 * p.N * p.H * p.W * (double)p.Cout * op.k_alg : 0.0); }   // the LDS-DMA family alone (bench.py's roofline kernel); small-batch launches are told apart by their f4 label
         if (e != hipSuccess) return fail(TD_ERR_HIP, "conv launch " + op.label + ": " + hipGetErrorString(e));
     }
     return TD_OK;
@@ -1200,8 +1216,8 @@ static const char* const kKnownOptions[] = {
     "plan_cache_mb", "plan_cache_max",
     // plan builder (speed only, or test hooks that force a tile shape; all part of the plan-cache key)
     "attn_mfma", "bn128_min_wgs", "glds", "glds_bn", "glds_bn64", "glds_dma1x1", "glds_min_wgs", "glds_round_aware", "glds_small_max_groups",
-    "glds_splitk", "glds_splitk_from_groups", "glds_splitk_max", "glds_splitk_min_groups", "glds_tiny", "glds_variant", "pp", "pp_min_items_per_cu",
-    "producer_act", "sb", "sb_max_glds_wgs", "sb_mt", "sb_nt", "sb_order", "sb_splitk", "sb_splitk_max", "sb_splitk_wgs", "sb_target_wgs", "splitk",
+    "glds_splitk", "glds_splitk_from_groups", "glds_splitk_max", "glds_splitk_min_groups", "glds_tiny", "glds_variant",
+    "producer_act", "s16", "s16_min_wgs", "sb", "sb_max_glds_wgs", "sb_mt", "sb_nt", "sb_order", "sb_splitk", "sb_splitk_max", "sb_splitk_wgs", "sb_target_wgs", "splitk",
     "splitk_target_wgs", "splitk_weighted", "walk_alternate"};
 int td_engine_set_option(td_engine* e, const char* key, int64_t value) {
     if (!e || !key) return fail(TD_ERR_ARG, "null");

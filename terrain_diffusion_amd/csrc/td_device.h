@@ -70,11 +70,11 @@ struct ConvParams {
     float res_inv_c;
     float res_scale;      // 0.7/sqrt(0.58) (conv weights carry 0.3/sqrt(0.58))
     float clip;           // <=0: no clip
-    float* out_sumsq;     // [parts][N*H*W] or null; parts: CoutPad/32 (conv_glds / conv_pp), n_ntiles*WAVES_N (conv_igemm), CoutPad/256 (split-K reduce)
+    float* out_sumsq;     // [parts][N*H*W] or null; parts: CoutPad/32 (conv_glds / conv_sb), CoutPad/16 (conv_s16), n_ntiles*WAVES_N (conv_igemm), CoutPad/256 (split-K reduce)
     float* partial;       // split-K workspace [ksplit][N*H*W][CoutPad] fp32
     void* out2;           // optional second output, same layout as out: mp_silu(out2_scale * out) -- the consumer's activation, done once here
     float out2_scale;
-    const void* zeros;    // >= 16 zero bytes in device memory: source of the halo outside the image for LDS-DMA patch staging (conv_pp.hip)
+    const void* zeros;    // >= 16 zero bytes in device memory: a readable page of zeros (was the halo source of the removed ping-pong flavour's LDS-DMA patch staging)
     // EPI_DPM_STEP (the U-Net's output conv inside the EDM sampler): the DPM-Solver++ update and the next step's input preconditioning run in
     // this conv's epilogue instead of a separate pass over F (dpmsolver.py:226-258, 454-561, 650-726) -- the conv result is the model output F
     float* dpm_x;         // sample, planar fp32 [N][Cout][H*W], updated in place

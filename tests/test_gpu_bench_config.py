@@ -3,7 +3,7 @@
 The driver line is BASELINE configs[2]: the full-size 30m base U-Net, 64 overlapping 64x64 windows batched per solver step, bf16.  At that
 batch the plan picks the 8-wave "big" conv tile variants, which no batch-1 test ever reaches.  These tests
   (a) run the base model at batch 64 and compare four samples of the batch with the oracle,
-  (b) force every legal conv tile shape / flavour (big, small, narrow, bn 96 / 128, persistent ping-pong) through the base model and
+  (b) force every legal conv tile shape / flavour (big, small, narrow, bn 96 / 128) through the base model and
       assert they agree BIT FOR BIT with each other, layer by layer (same K order, same MFMA -- DESIGN.md's claim),
   (c) run configs[2] end to end (8x8 grid, 20 steps) and compare four windows before the blend with the oracle plus the blended
       canvas with an independent blend of the engine's own windows.
@@ -84,7 +84,7 @@ def _forward_with(eng, m, x, t, c, n, **opts):
         opts = dict(opts, sb=opts.get("sb", 0))
         for k, v in opts.items():
             eng.set_option(k, v)
-            prev[k] = {"glds_variant": -1, "glds_bn": 0, "pp": 0, "glds_splitk": 1, "glds_dma1x1": 1, "sb": 1}[k]
+            prev[k] = {"glds_variant": -1, "glds_bn": 0, "glds_splitk": 1, "glds_dma1x1": 1, "sb": 1}[k]
         eng.set_option("profile", 1)
         eng.profile_read(reset=True)
         y = m(x, t, [c])
@@ -102,7 +102,7 @@ def _forward_with(eng, m, x, t, c, n, **opts):
 @pytest.mark.parametrize("n", [64, 8])
 def test_conv_tile_variants_bit_identical(td, base, n):
     """(b) every legal tile shape of the LDS-DMA conv (8 waves x 256 px / 4 waves x 128 px, 16-wide and the narrow 8x8 x 4 / x 2 image
-    tiles, couts in 96s / 128s) and the persistent ping-pong flavour accumulate every output in the same K order with the same MFMA:
+    tiles, couts in 96s / 128s) accumulates every output in the same K order with the same MFMA:
     the outputs of the whole network and of eight layers spread over the four resolution levels must be bit-identical.  That includes the
     pixel-norm statistic: sums of squares are kept per 32-cout MFMA block, so the consumer adds the same partials in the same order whatever
     tile shape produced them (round 2: they used to be kept per cout tile, which made bn 96 and bn 128 differ in the last bits).  Split-K
@@ -115,13 +115,12 @@ def test_conv_tile_variants_bit_identical(td, base, n):
     t = torch.full((n,), 0.7)
     arms = {"auto": dict(glds_splitk=0), "big": dict(glds_splitk=0, glds_variant=0), "small": dict(glds_splitk=0, glds_variant=1),
             "big/bn96": dict(glds_splitk=0, glds_variant=0, glds_bn=96), "small/bn128": dict(glds_splitk=0, glds_variant=1, glds_bn=128),
-            "pingpong": dict(glds_splitk=0, pp=2),
             # round 3: 1x1 K-segments (the decoder's fused skip convs) are streamed by LDS-DMA; the register-staged path is the other arm
             "reg1x1": dict(glds_splitk=0, glds_dma1x1=0), "reg1x1/big": dict(glds_splitk=0, glds_dma1x1=0, glds_variant=0),
             "reg1x1/small/bn128": dict(glds_splitk=0, glds_dma1x1=0, glds_variant=1, glds_bn=128)}
     res = {k: _forward_with(eng, m, x, t, c, n, **o) for k, o in arms.items()}
-    seen = {k: {tag for l in res[k][2] for tag in (" f2b ", " f2s ", " f3p ", "bn96", "bn128") if tag in l} for k in res}
-    assert " f2b " in seen["big"] and " f2s " in seen["small"] and " f3p " in seen["pingpong"], seen
+    seen = {k: {tag for l in res[k][2] for tag in (" f2b ", " f2s ", "bn96", "bn128") if tag in l} for k in res}
+    assert " f2b " in seen["big"] and " f2s " in seen["small"], seen
     assert all(" f2s " not in l for l in res["big"][2] if "8x8" in l and " f2" in l), "narrow big variant <8,8,4,...> must run in the 'big' arm"
     y0, a0, _ = res["auto"]
     assert torch.isfinite(y0).all() and float(y0.abs().mean()) > 1e-3
@@ -278,9 +277,9 @@ def test_fp16_tile_variants_bit_identical_and_close_to_bf16(td):
     x, c = _batch_inputs(8, seed=9)
     t = torch.full((8,), 0.7)
     outs = {}
-    for k, o in {"big": dict(glds_splitk=0, glds_variant=0), "small": dict(glds_splitk=0, glds_variant=1), "pingpong": dict(glds_splitk=0, pp=2)}.items():
+    for k, o in {"big": dict(glds_splitk=0, glds_variant=0), "small": dict(glds_splitk=0, glds_variant=1)}.items():
         outs[k] = _forward_with(eng, m, x.cuda(), t, c.cuda(), 8, **o)[0]
-    assert torch.equal(outs["big"], outs["small"]) and torch.equal(outs["big"], outs["pingpong"])
+    assert torch.equal(outs["big"], outs["small"])
     with torch.no_grad():
         ref = OracleUnet(BASE_CONFIG, sd)(x[:2], t[:2], [c[:2]])
     err = rel_rms(outs["big"][:2].cpu().numpy(), ref.numpy())

@@ -257,6 +257,53 @@ def test_caller_supplied_stream_orders_engine_work_without_host_sync(td):
     m.close()
 
 
+def test_unknown_engine_option_is_refused(td):
+    """Round-4 review: td_engine_set_option stored any key ("batch_invarient" was accepted and never read -- silently losing the sharded bit-identity)."""
+    from terrain_diffusion_amd.engine import get_engine
+    from terrain_diffusion_amd._lib import lib
+    eng = get_engine("cuda")
+    with pytest.raises(RuntimeError, match="unknown engine option"):
+        eng.set_option("batch_invarient", 1)
+    assert b"batch_invarient" in lib().td_last_error()
+    eng.set_option("batch_invariant", 0)                # the real key is still accepted
+
+
+def test_on_stream_is_reentrant_and_ordered_behind_the_previous_stream(td):
+    """Round-4 advisor: (1) entering on_stream(side) did not order `side` behind torch's previously current stream -- inputs produced there just
+    before entry were read unordered (ptr() no longer synchronises once the engine shares torch's current stream); (2) an inner on_stream block
+    (the sharded samplers enter one) dropped the caller's stream and enqueue-only mode for the rest of the caller's block."""
+    from oracle.unet import synth_state_dict, tiny_config
+    from terrain_diffusion_amd.engine import get_engine, engine_on_current_stream
+    from terrain_diffusion_amd.sampling import sample_tiles_edm
+    eng = get_engine("cuda")
+    cfg = tiny_config(64, 1)
+    m = td.EDMUnet2D(**cfg, dtype="bf16").load_state_dict(synth_state_dict(cfg, seed=77))
+    sch = td.EDMDPMSolverMultistepScheduler()
+    sch.set_timesteps(6)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    base = torch.randn(4, 5, 16, 16, device="cuda", generator=g)
+    cond = torch.randn(4, 58, device="cuda", generator=g)
+    ref = sample_tiles_edm(m, sch, (base * 2.0).contiguous(), cond, 6)
+    torch.cuda.synchronize()
+    outer, inner = torch.cuda.Stream(), torch.cuda.Stream()
+    big = torch.randn(4096, 4096, device="cuda")
+    for _ in range(20):
+        big = big @ big * 1e-3                          # ~ms of work queued on the DEFAULT stream ...
+    x = (base * 2.0).contiguous()                       # ... in front of the producer of the engine's input, still on the default stream
+    with eng.on_stream(outer):                          # must wait for the default stream (no host synchronisation in between)
+        y = sample_tiles_edm(m, sch, x.clone(), cond, 6)   # (the sampler works in place)
+        with eng.on_stream(inner, asynchronous=False):
+            assert engine_on_current_stream("cuda") and eng.stream == inner.cuda_stream
+            y2 = sample_tiles_edm(m, sch, x.clone(), cond, 6)
+        # back in the outer block: the caller's stream and enqueue-only mode are restored
+        assert eng.stream == outer.cuda_stream and engine_on_current_stream("cuda") and eng._async
+        y3 = sample_tiles_edm(m, sch, x.clone(), cond, 6)
+    torch.cuda.synchronize()
+    assert eng.stream not in (outer.cuda_stream, inner.cuda_stream) and not eng._async
+    assert torch.equal(y, ref) and torch.equal(y2, ref) and torch.equal(y3, ref)
+    m.close()
+
+
 def test_pano_denoise_ddim_cfg_step_vs_oracle(td):
     """BASELINE configs[0] (annotated_infinite_panorama.py:125-134): the classifier-free-guidance mix + DDIM update on the engine
     (td_ddim_cfg_step, driven by pano.denoise with a stand-in denoiser -- SD-v1.5's UNet2DCondition is third-party) against oracle/ddim.py's

@@ -59,14 +59,16 @@ def test_single_tile_forward_runs_on_the_small_batch_flavour_and_matches_the_ref
     y = m(*args)
     err = rel_rms(y.cpu().numpy(), golden("unet")["base_out"])
     fl = _flavours(eng, m, args)
-    n4 = sum(v.startswith("f4") for v in fl.values())
-    print(f"batch 1 {dtype}: {n4} of {len(fl)} conv launches on the small-batch flavour; rel-RMS vs reference {err:.3e}")
+    n4 = sum(v.startswith(("f4", "f5")) for v in fl.values())
+    n5 = sum(v.startswith("f5") for v in fl.values())
+    print(f"batch 1 {dtype}: {n4} of {len(fl)} conv launches on the small-batch flavours ({n5} of them on the 64 px x 16 cout one); rel-RMS vs reference {err:.3e}")
     assert err < tol
     assert n4 >= 70, fl   # every conv that used to split K over workgroups (78 of 79 at batch 1)
+    assert n5 >= 15, fl   # round 5: the 16x16 level (19 convs) no longer splits K over workgroups (at 8x8 that stays the faster plan: 48 workgroups of 16 couts lose)
     try:   # the same forward with the flavour switched off: conv_glds + split-K, same bound, and the two agree to bf16 rounding
         eng.set_option("sb", 0)
         y0 = m(*args)
-        assert not any(v.startswith("f4") for v in _flavours(eng, m, args).values())
+        assert not any(v.startswith(("f4", "f5")) for v in _flavours(eng, m, args).values())
     finally:
         eng.set_option("sb", 1)
     assert rel_rms(y0.cpu().numpy(), golden("unet")["base_out"]) < tol
@@ -91,6 +93,51 @@ def test_every_tile_shape_of_the_small_batch_flavour(td, orc, golden, base, mt, 
     err = rel_rms(y.cpu().numpy(), golden("unet")["base_out"])
     print(f"sb tile m{mt} n{nt}: rel-RMS vs reference {err:.3e}")
     assert err < 2e-2
+
+
+def _split_k_launches(eng, model, args):
+    """conv launches of one forward that split K over workgroups (ks > 1 in the profile label: each has a reduce launch behind it)"""
+    import re
+    eng.set_option("profile", 1); eng.profile_read(reset=True)
+    try:
+        model(*args)
+        rows = eng.profile_ops()
+    finally:
+        eng.set_option("profile", 0); eng.profile_read(reset=True)
+    return [r[0] for r in rows if (m_ := re.search(r" ks(\d+) ", r[0])) and int(m_.group(1)) > 1]
+
+
+@pytest.mark.parametrize("dtype,tol", [("bf16", 2e-2), ("fp16", 4e-3)])
+def test_deep_level_flavour_everywhere_and_no_reduce_launch_in_a_single_tile_forward(td, orc, golden, base, dtype, tol):
+    """conv_s16.hip (64 px x 16 couts on 16x16x32 MFMAs, K split over the waves of the workgroup only).  (1) default plan of a single tile: the 16x16
+    level no longer splits K over workgroups (44 reduce launches per forward in round 4, 25 now: the 8x8 level keeps them -- measured faster there,
+    profiles/r05_conv_s16_deep_levels.txt); (2) option s16 = 2 forces it on every layer the small-batch
+    flavours apply to (3x3 + fused 1x1 segments, pixel-norm prologue, every epilogue, the fp32 output conv with the generic epilogue): the
+    reference bound holds on its own; (3) s16 = 0 restores the round-4 plan."""
+    from terrain_diffusion_amd.engine import get_engine
+    eng = get_engine("cuda")
+    args = _inputs(orc, 1)
+    m = base[dtype]
+    sk = _split_k_launches(eng, m, args)
+    assert 0 < len(sk) <= 26 and all("8x8" in l for l in sk), sk
+    try:
+        eng.set_option("s16", 2)
+        y = m(*args)
+        fl = _flavours(eng, m, args)
+    finally:
+        eng.set_option("s16", 1)
+    assert sum(v == "f5c16" for v in fl.values()) >= 70, fl
+    err = rel_rms(y.cpu().numpy(), golden("unet")["base_out"])
+    print(f"s16 everywhere, {dtype}: rel-RMS vs reference {err:.3e}")
+    assert err < tol
+    try:
+        eng.set_option("s16", 0)
+        y0 = m(*args)
+        assert not any(v.startswith("f5") for v in _flavours(eng, m, args).values())
+        assert len(_split_k_launches(eng, m, args)) >= 40
+    finally:
+        eng.set_option("s16", 1)
+    assert rel_rms(y0.cpu().numpy(), golden("unet")["base_out"]) < tol
 
 
 def test_small_batches_match_the_single_tile_results(td, orc, base):
@@ -120,15 +167,15 @@ def test_ragged_map_and_workgroup_order(td, orc):
         ref = m(x, t, [c])
     finally:
         eng.set_option("glds", 1); eng.set_option("splitk", 1)
-    for order in (0, 1):
+    for order, s16 in ((0, 1), (1, 1), (0, 2), (1, 2)):   # s16 = 2: the 64 px x 16 cout flavour on every eligible layer (ragged 36 / 18 / 9-wide maps)
         try:
-            eng.set_option("sb_order", order)
+            eng.set_option("sb_order", order); eng.set_option("s16", s16)
             y = m(x, t, [c])
             fl = _flavours(eng, m, (x, t, [c]))
         finally:
-            eng.set_option("sb_order", -1)   # back to the planner's choice
-        assert any(v.startswith("f4") for v in fl.values()), fl
+            eng.set_option("sb_order", -1); eng.set_option("s16", 1)   # back to the planner's choice
+        assert any(v.startswith("f4" if s16 == 1 else "f5") for v in fl.values()), fl
         e = rel_rms(y.cpu().numpy(), ref.cpu().numpy())
-        print(f"ragged 72x72, sb_order {order}: rel-RMS vs the per-tap flavour {e:.3e}")
-        assert e < 1e-2, (order, e)
+        print(f"ragged 72x72, sb_order {order}, s16 {s16}: rel-RMS vs the per-tap flavour {e:.3e}")
+        assert e < 1e-2, (order, s16, e)
     m.close()

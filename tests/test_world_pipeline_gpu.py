@@ -169,6 +169,25 @@ def test_device_window_tensor_integer_indices_drop_their_dimension(td, models):
     w.close()
 
 
+def test_large_region_read_is_cut_along_the_window_grid_bit_identically(td, models):
+    """Round-4 advisor: a single large region went through the region-gather kernel with EVERY window it touches listed per pixel.  Large regions are
+    now cut into cells of <= MAX_REGION_WINDOWS windows (DeviceWindowTensor._gather_cells); same windows, same order: the same bits."""
+    w = _world(td, models)
+    t = w.latents
+    y0, x0, h, wd = -37, 11, 300, 333            # straddles the origin, not aligned to the window grid, dozens of windows
+    assert len(t._windows_for([0, y0, x0], [t.channels + 1, y0 + h, x0 + wd])) > t.MAX_REGION_WINDOWS
+    cut = t[:, y0:y0 + h, x0:x0 + wd]
+    keep, type(t).MAX_REGION_WINDOWS = t.MAX_REGION_WINDOWS, 1 << 30
+    try:
+        whole = t[:, y0:y0 + h, x0:x0 + wd]      # the one-region path
+    finally:
+        type(t).MAX_REGION_WINDOWS = keep
+    assert cut.shape == whole.shape == (t.channels + 1, h, wd) and torch.equal(cut, whole)
+    sub = t[:, y0 + 50:y0 + 90, x0 + 60:x0 + 100]   # a small region (one-region path) agrees with the crop of the large one
+    assert torch.equal(sub, cut[:, 50:90, 60:100])
+    w.close()
+
+
 def test_world_pipeline_to_is_loud(td, models):
     """Round-2 review: `to()` silently ignored its argument.  The resident device is accepted, everything else is refused."""
     w = _world(td, models)

@@ -10,7 +10,6 @@
 #include <array>
 #include "conv_igemm.hip"
 #include "conv_glds.hip"
-#include "conv_pp.hip"
 using namespace td;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 __global__ void __launch_bounds__(256) bench_prefetch_kernel(const uint4* __restrict__ w, size_t n16, uint4* sink) {
@@ -40,7 +39,7 @@ int main(int argc, char** argv) {
     for (auto& v : hw) { const unsigned r_ = rnd(); v = 0x3c00 + (r_ & 0xff) + (((r_ >> 8) & 1) << 15); }          // small
     CK(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
     if (ksplit > 1) CK(hipMalloc(&partial, (size_t)ksplit * M * Cout * 4));
-#if defined(TD_TRACE) || defined(TD_PP_TRACE)
+#ifdef TD_TRACE
     const size_t trace_n = (size_t)65536 * 12 * 16;
     CK(hipMalloc(&partial, trace_n * 8)); CK(hipMemset(partial, 0, trace_n * 8));
 #endif
@@ -54,7 +53,7 @@ int main(int argc, char** argv) {
         p.nseg = 2; p.seg[1].src = x2; p.seg[1].C = Cin2; p.seg[1].cstride = Cin2; p.seg[1].Hs = H; p.seg[1].Ws = W; p.seg[1].taps = taps2; p.seg[1].xform = 0; p.seg[1].scale = 1.f;
     }
     p.dma1x1 = getenv("TD_DMA1X1") ? atoi(getenv("TD_DMA1X1")) : 1;
-    bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4) ? 4 : 2) : 1; int TH = flavor == 8 ? 4 : ((flavor == 2 || flavor == 4 || flavor == 5) && !narrow) ? 16 : 8;  // flavor 8 = conv_glds variant 2 (tiny tile)
+    bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4) ? 4 : 2) : 1; int TH = flavor == 8 ? 4 : ((flavor == 2 || flavor == 4) && !narrow) ? 16 : 8;  // flavor 8 = conv_glds variant 2 (tiny tile)
     p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH; p.img_groups = (N + NIMG - 1) / NIMG; p.n_ntiles = Cout / bn;
     p.epi = epi; p.out = out; p.out_cstride = Cout;
     { void* z; CK(hipMalloc(&z, 4096)); CK(hipMemset(z, 0, 4096)); p.zeros = z; }
@@ -69,7 +68,7 @@ int main(int argc, char** argv) {
     if (getenv("TD_EXTRA_LDS")) g_bench_extra_lds = atoi(getenv("TD_EXTRA_LDS"));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto L = [&](const ConvParams& q) { return flavor == 8 ? launch_conv_glds(q, 1, narrow, bn, 2, st) : flavor == 5 ? launch_conv_pp(q, 1, bn, 256, st) : flavor >= 2 ? launch_conv_glds(q, 1, narrow, bn, flavor - 2, st) : launch_conv(q, 1, narrow, bn, flavor, st); };
+    auto L = [&](const ConvParams& q) { return flavor == 8 ? launch_conv_glds(q, 1, narrow, bn, 2, st) : flavor >= 2 ? launch_conv_glds(q, 1, narrow, bn, flavor - 2, st) : launch_conv(q, 1, narrow, bn, flavor, st); };
     for (int i = 0; i < 4; ++i) CK(L((chain && (i & 1)) ? p2 : p));
     CK(hipStreamSynchronize(st));
     const int reps = 20;
@@ -120,35 +119,6 @@ int main(int argc, char** argv) {
         size_t bad = 0, nz = 0; for (size_t i = 0; i < o0.size(); ++i) { bad += o0[i] != o1[i]; nz += (o1[i] & 0x7fff) != 0; }
         printf("  check vs bn%d small: %zu / %zu outputs differ, nonzero outputs %zu\n", bn0, bad, o0.size(), nz);
     }
-    if (flavor == 5) {  // bit-exactness of the persistent ping-pong flavour against the LDS-DMA flavour (same K order, same MFMA)
-        std::vector<uint16_t> o5(M * Cout), o2(M * Cout);
-        CK(hipMemset(out, 0, M * Cout * 2));
-        CK(launch_conv_pp(p, 1, bn, 256, st)); CK(hipStreamSynchronize(st));
-        CK(hipMemcpy(o5.data(), out, o5.size() * 2, hipMemcpyDeviceToHost));
-        std::vector<float> s5, s2;
-        if (p.out_sumsq) { s5.resize(M * (Cout / 32)); CK(hipMemcpy(s5.data(), p.out_sumsq, s5.size() * 4, hipMemcpyDeviceToHost)); }
-        CK(hipMemset(out, 0, M * Cout * 2));
-        ConvParams q = p; q.tiles_y = (H + 15) / 16;
-        CK(launch_conv_glds(q, 1, narrow, bn, 0, st)); CK(hipStreamSynchronize(st));
-        CK(hipMemcpy(o2.data(), out, o2.size() * 2, hipMemcpyDeviceToHost));
-        if (p.out_sumsq) { s2.resize(M * (Cout / 32)); CK(hipMemcpy(s2.data(), p.out_sumsq, s2.size() * 4, hipMemcpyDeviceToHost)); }
-        size_t bad = 0, first = 0; for (size_t i = 0; i < o5.size(); ++i) if (o5[i] != o2[i]) { if (!bad) first = i; ++bad; }
-        size_t bads = 0; for (size_t i = 0; i < s5.size(); ++i) if (memcmp(&s5[i], &s2[i], 4)) ++bads;
-        size_t nz = 0; for (auto v : o2) nz += (v & 0x7fff) != 0;
-        printf("  check vs conv_glds: %zu / %zu outputs differ (first at %zu: pixel %zu cout %zu), sumsq diffs %zu, nonzero outputs %zu\n", bad, o5.size(), first, first / Cout, first % Cout, bads, nz);
-    }
-#ifdef TD_PP_TRACE
-    if (flavor == 5) {
-        std::vector<unsigned long long> tb((size_t)256 * 8 * 16);
-        CK(hipMemcpy(tb.data(), partial, tb.size() * 8, hipMemcpyDeviceToHost));
-        double s[7] = {0, 0, 0, 0, 0, 0, 0}, g[2][7] = {{0}};
-        for (int w = 0; w < 256 * 8; ++w) for (int j = 0; j < 7; ++j) { s[j] += (double)tb[(size_t)w * 16 + j]; g[(w & 7) >> 2][j] += (double)tb[(size_t)w * 16 + j]; }
-        const double nw = 256.0 * 8, tiles = (double)p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups / 256.0, taps = tiles * ksteps;
-        printf("  pp trace (shader cycles, mean per wave; %.1f tiles, %.0f taps per workgroup): total %.0f | epilogue %.0f (%.0f per tile)  load phase %.0f (%.0f/tap)  barrier-after-load %.0f (%.0f/tap)  mfma phase %.0f (%.0f/tap)  barrier-after-mfma %.0f (%.0f/tap) | clock %.0f MHz\n",
-               tiles, taps, s[5] / nw, s[0] / nw, s[0] / nw / tiles, s[1] / nw, s[1] / nw / taps, s[2] / nw, s[2] / nw / taps, s[3] / nw, s[3] / nw / taps, s[4] / nw, s[4] / nw / taps, 100.0 * s[5] / s[6]);
-        for (int q = 0; q < 2; ++q) printf("    group %d: epilogue %.0f  load %.0f/tap  bar1 %.0f/tap  mfma %.0f/tap  bar2 %.0f/tap\n", q, g[q][0] / (nw / 2) / tiles, g[q][1] / (nw / 2) / taps, g[q][2] / (nw / 2) / taps, g[q][3] / (nw / 2) / taps, g[q][4] / (nw / 2) / taps);
-    }
-#endif
 #ifdef TD_TRACE
     {
         int wgs = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups; const int nw = flavor == 4 ? 12 : (flavor == 3 ? 4 : 8), TS = 16;

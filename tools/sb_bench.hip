@@ -1,7 +1,7 @@
 // Standalone correctness + timing harness of the small-batch conv flavour (conv_sb.hip) against the per-tap flavour (conv_igemm.hip, bf16, no split-K)
 // and the split-K LDS-DMA flavour (conv_glds.hip) on one synthetic layer with random data.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I terrain_diffusion_amd/csrc tools/sb_bench.hip -o tools/sb_bench.out
-//   ./sb_bench.out N H W Cin Cout mt nt [Cin1x1 epi xform order resample glds_ks]
+//   ./sb_bench.out N H W Cin Cout mt nt [Cin1x1 epi xform order resample glds_ks]      (mt = 0: the 64 px x 16 cout flavour of conv_s16.hip)
 //     Cin: channels of the 3x3 segment (0 = none), Cin1x1: channels of a second, 1x1 segment with its own source; epi 0 plain 1 emb-silu 2 residual;
 //     xform 0 none 1 mp_silu 2 pixel-norm + mp_silu (3x3 segment); order = sb_order; resample 0 keep 2 up (3x3 source at half resolution);
 //     glds_ks: split-K factor of the conv_glds comparison run (0 = skip it)
@@ -17,6 +17,7 @@
 #include "conv_glds.hip"
 #endif
 #include "conv_sb.hip"
+#include "conv_s16.hip"
 using namespace td;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 static float bf2f(uint16_t v) { uint32_t b = (uint32_t)v << 16; float f; memcpy(&f, &b, 4); return f; }
@@ -67,14 +68,15 @@ int main(int argc, char** argv) {
     if (epi == EPI_RESIDUAL) {
         void* r; std::vector<uint16_t> hr(M * Cout); for (auto& v : hr) v = 0x3f00 + (rand() & 0xff) + ((rand() & 1) << 15);
         CK(hipMalloc(&r, hr.size() * 2)); CK(hipMemcpy(r, hr.data(), hr.size() * 2, hipMemcpyHostToDevice));
-        CK(hipMalloc(&ssq, M * (CoutPad / 32 + 8) * 4)); CK(hipMalloc(&ssq_ref, M * (CoutPad / 32 + 8) * 4));
+        CK(hipMalloc(&ssq, M * (CoutPad / 16 + 8) * 4)); CK(hipMalloc(&ssq_ref, M * (CoutPad / 16 + 8) * 4));
         p.res = r; p.res_cstride = Cout; p.res_Hs = H; p.res_Ws = W; p.res_scale = 0.9f; p.clip = 256.f;
     }
     void *o2 = nullptr, *o2_ref = nullptr;
     if (A(14, 0)) { CK(hipMalloc(&o2, M * Cout * 2)); CK(hipMalloc(&o2_ref, M * Cout * 2)); p.out2_scale = 1.3f; }
     if (!conv_set_kbounds(p, true)) { printf("bad split-K\n"); return 1; }
     hipStream_t st; CK(hipStreamCreate(&st));
-    CK(launch_sb_repack(w, wsb, CoutPad, n3, g1, st));
+    const bool s16 = mt == 0;
+    if (s16) CK(launch_s16_repack(w, wsb, CoutPad, n3, g1, st)); else CK(launch_sb_repack(w, wsb, CoutPad, n3, g1, st));
     const bool narrow = W < 16;
     // ---- reference: per-tap flavour, 8x16 (8x8x2) tile, bn 64, no split-K
     ConvParams pr = p; pr.out = out_ref; pr.out_sumsq = ssq_ref; pr.out2 = o2_ref;
@@ -83,14 +85,15 @@ int main(int argc, char** argv) {
     CK(launch_conv(pr, 1, narrow, 64, 0, st));
     // ---- sb
     ConvParams ps = p; ps.out = out; ps.out_sumsq = ssq; ps.out2 = o2; ps.wpack_sb = wsb; ps.sb_n3 = n3; ps.sb_order = order;
-    { const int TW = narrow ? 8 : 16, TH = narrow ? (mt == 2 ? 8 : 4) : (mt == 2 ? 4 : 2); ps.tiles_x = (W + TW - 1) / TW; ps.tiles_y = (H + TH - 1) / TH; ps.img_groups = N; ps.n_ntiles = CoutPad / (32 * nt); }
+    { const int TW = narrow ? 8 : 16, TH = narrow ? ((mt == 2 || s16) ? 8 : 4) : ((mt == 2 || s16) ? 4 : 2); ps.tiles_x = (W + TW - 1) / TW; ps.tiles_y = (H + TH - 1) / TH; ps.img_groups = N; ps.n_ntiles = s16 ? CoutPad / 16 : CoutPad / (32 * nt); }
+    auto LSB = [&](const ConvParams& q_) { return s16 ? launch_conv_s16(q_, 1, narrow, st) : launch_conv_sb(q_, 1, narrow, mt, nt, st); };
     const int sb_ks = A(15, 1);   // split-K over workgroups on top of the in-workgroup split (+ reduce launch)
     if (sb_ks > 1) {
         float* part; CK(hipMalloc(&part, (size_t)sb_ks * M * CoutPad * 4)); ps.partial = part; ps.ksplit = sb_ks;
         if (!conv_set_kbounds(ps, true)) { printf("bad sb split-K\n"); return 1; }
     }
     CK(hipMemset(out, 0, M * CoutPad * 4));
-    CK(launch_conv_sb(ps, 1, narrow, mt, nt, st));
+    CK(LSB(ps));
     CK(hipStreamSynchronize(st));
     {
         std::vector<uint16_t> a(M * Cout), b(M * Cout);
@@ -100,6 +103,10 @@ int main(int argc, char** argv) {
         printf("  sb vs per-tap: rel-RMS %.3e  max|d| %.3e (rms %.3e)  outside 2%%: %zu / %zu  nonzero %zu\n", sqrt(se / std::max(sr, 1e-30)), mx, sqrt(sr / a.size()), nbad, a.size(), nz);
         if (ssq) {
             std::vector<float> sa(M * (CoutPad / 32)), sb_(M * (CoutPad / 32));
+            if (s16) {   // one plane per 16 couts: planes 2k and 2k + 1 together are the 32-cout partial of the other flavours
+                std::vector<float> s2(M * (CoutPad / 16)); CK(hipMemcpy(s2.data(), ssq, s2.size() * 4, hipMemcpyDeviceToHost));
+                for (int k = 0; k < CoutPad / 32; ++k) for (size_t i = 0; i < M; ++i) sa[k * M + i] = s2[(2 * k) * M + i] + s2[(2 * k + 1) * M + i];
+            } else
             CK(hipMemcpy(sa.data(), ssq, sa.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(sb_.data(), ssq_ref, sb_.size() * 4, hipMemcpyDeviceToHost));
             // the per-tap flavour keeps one partial per (cout tile, wave column) = per 32 couts at bn 64 with 2 wave columns: same decomposition
             double e2 = 0, r2 = 0; for (size_t i = 0; i < sa.size(); ++i) { e2 += (sa[i] - sb_[i]) * (double)(sa[i] - sb_[i]); r2 += (double)sb_[i] * sb_[i]; }
@@ -123,8 +130,8 @@ int main(int argc, char** argv) {
         return acc / r * 1e3;
     };
     const double flop = 2.0 * M * Cout * ((double)Cin * 9 + Cin1), wmb = (double)ksteps * CoutPad * 128 * 1e-6;
-    const float t_sb = timeit([&] { return launch_conv_sb(ps, 1, narrow, mt, nt, st); });
-    const float c_sb = cold([&] { return launch_conv_sb(ps, 1, narrow, mt, nt, st); });
+    const float t_sb = timeit([&] { return LSB(ps); });
+    const float c_sb = cold([&] { return LSB(ps); });
     printf("N%d %dx%d C%d+%d(1x1) -> %d mt%d nt%d epi%d xf%d ord%d rs%d ks%d | sb: hot %.1f us (%.0f TF/s)  cold %.1f us (%.0f GB/s of %.2f MB weights)  wgs=%d\n", N, H, W, Cin, Cin1, Cout, mt, nt, epi, xform, order, resample, sb_ks,
            t_sb, flop / t_sb * 1e-6, c_sb, wmb / c_sb * 1e3, wmb, ps.n_ntiles * ps.tiles_x * ps.tiles_y * ps.img_groups * sb_ks);
 #ifdef SB_WITH_GLDS
