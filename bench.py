@@ -33,7 +33,7 @@ WEIGHT_BYTES_BF16 = 253_688_037 * 2  # algorithmic minimum HBM bytes per forward
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-PROFILE_JSON = os.path.join(ROOT, "profiles", "r04_hbm_traffic_and_mfma_util.json")   # stamped with the library build id it was collected with
+PROFILE_JSON = os.path.join(ROOT, "profiles", "r05_hbm_traffic_and_mfma_util.json")   # stamped with the library build id it was collected with
 
 # terrain-diffusion-30m base model (configs/diffusion_base/30m/diffusion_192-3.cfg:54-68)
 BASE_CONFIG = dict(image_size=512, in_channels=5, out_channels=5, model_channels=192, model_channel_mults=[1, 2, 3, 4], layers_per_block=3,
@@ -215,7 +215,11 @@ def main():
             one_step(10_000)
             sync()
             g_ms, g_flop, g_n = eng.profile_read_glds(reset=True)
-            sb_rows = [(float(re.search(r" gf([0-9.]+)", l_).group(1)), ms_, n_) for l_, ms_, n_ in eng.profile_ops() if re.search(r" f[45]\w* bn", l_)]
+            ops_ = eng.profile_ops()
+            sb_rows = [(float(re.search(r" gf([0-9.]+)", l_).group(1)), ms_, n_) for l_, ms_, n_ in ops_ if re.search(r" f[45]\w* bn", l_)]
+            # algorithmic HBM bytes per launch of the roofline family (every source tensor once at its own resolution, residual, weights and outputs
+            # once): with the optional pre-activated second output counted (what the launches are asked to write) and, strictly, without it
+            g_rows = [(float(re.search(r" mb([0-9.]+)", l_).group(1)), float(re.search(r" mbs([0-9.]+)", l_).group(1)), n_) for l_, ms_, n_ in ops_ if re.search(r" f2\w* bn", l_)]
             conv_ms, conv_n, other_ms, other_n = eng.profile_read(reset=True)
             eng.set_option("profile", 0)
             roof.update({"all_conv_kernels_ms_per_step": round(conv_ms, 3), "all_conv_launches_per_step": conv_n,
@@ -231,6 +235,10 @@ def main():
                 share = g_ms / (conv_ms + other_ms)
                 iso = {"achieved": round(ach, 2), "frac": round(ach / peak, 4), "avg_launch_us": round(g_ms / g_n * 1e3, 3), "kernel_ms_per_step": round(g_ms, 3)}
                 roof.update({"launches_per_step": g_n, "flop_per_launch": round(g_flop / g_n), "share_of_unet_kernel_time": round(share, 4), "lanes": lanes})
+                if g_rows:
+                    nl_ = sum(n_ for _, _, n_ in g_rows)
+                    roof["traffic_algorithmic"] = round(sum(mb_ * n_ for mb_, _, n_ in g_rows) / nl_ * 1e6)
+                    roof["traffic_algorithmic_strict"] = round(sum(mbs_ * n_ for _, mbs_, n_ in g_rows) / nl_ * 1e6)
                 if lanes == 1:
                     roof.update(iso)
                 else:
@@ -269,6 +277,9 @@ def main():
                         if n_:
                             roof["traffic"] = round(sum(v["dispatches"] * (v["hbm_read_bytes_per_launch"] + v.get("hbm_write_bytes_per_launch", 0)) for v in ks_) / n_)
                             roof["traffic_source"] = os.path.relpath(PROFILE_JSON, ROOT)
+                            if roof.get("traffic_algorithmic_strict"):
+                                roof["traffic_over_algorithmic"] = round(roof["traffic"] / roof["traffic_algorithmic"], 3)
+                                roof["traffic_over_algorithmic_strict"] = round(roof["traffic"] / roof["traffic_algorithmic_strict"], 3)
         else:
             roof.update({"achieved": roof["end_to_end_achieved"], "frac": roof["end_to_end_frac"]})
         result["roofline"] = roof
@@ -284,10 +295,10 @@ def main():
             result["single_tile_mp_per_s"] = round(0.262144 / lat, 3)
             hbm = E * WEIGHT_BYTES_BF16 / lat / 1e9
             result["roofline_single_tile"] = {"bound": "hbm", "achieved": round(hbm, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(hbm / PEAK_HBM_GBS, 4),
-                                              "kernel": "td::conv_sb_kernel (small-batch flavour: K split over the waves of a workgroup, no fp32 partial planes in HBM "
-                                                        "above the 16x16 level) + td::conv_splitk_reduce_kernel behind the 8x8 / 16x16 levels",
+                                              "kernel": "td::conv_sb_kernel (small-batch flavour: K split over the waves of a workgroup) at the 64x64 / 32x32 levels, td::conv_s16_kernel "
+                                                        "(64 px x 16 couts, no split-K over workgroups) at the 16x16 level, conv_sb + td::conv_splitk_reduce_kernel at the 8x8 level",
                                               "note": f"algorithmic bytes = {E} forwards x {WEIGHT_BYTES_BF16} B of bf16 weights (activations of one tile are negligible); "
-                                                      "measured HBM bytes per forward: profiles/r04_batch_sweep.txt"}
+                                                      "measured HBM bytes per forward: profiles/r05_batch_sweep.txt"}
 
         if world == 1 and not args.no_latency and workload == "grid8" and args.dtype == "bf16":
             # N = 1 point of the STRONG-scaling workload the driver runs at N > 1 (grid32, BASELINE configs[3]): one full step, timed live in this

@@ -133,7 +133,7 @@ def run_cascade(args, eng, dev, rank, world):
                    "requests_per_step": split.get("requests_per_step"), "requests_per_rank": per_rank,
                    "engine_calls": "enqueue-only on one stream shared with torch (Engine.on_stream)" if enqueue_only else "synchronous (complete on return)"},
         "batch_sweep": {"what": "base U-Net forward (193.654 GFLOP per tile) at the latent stage's batch sizes, eager launches, wall ms per forward; "
-                                "the full 1 ... 64 sweep with HBM bytes is profiles/r04_batch_sweep.txt", "by_batch": sweep},
+                                "the full 1 ... 64 sweep with HBM bytes is profiles/r05_batch_sweep.txt", "by_batch": sweep},
         "roofline": {"bound": "mfma", "kernel": "td::conv_glds_kernel (all stages)", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "achieved": round(tflops, 2),
                      "frac": round(tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
                      "note": "end to end over the algorithmic 15.24 TFLOP per decoded MP (recomputed evicted windows are NOT counted as useful work)",

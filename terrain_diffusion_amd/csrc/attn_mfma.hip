@@ -74,6 +74,39 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(const TIN* __restrict__ 
     }
 }
 
+// The U-Net's own case in ONE launch (round 5; three launches of the generic kernel cost 2.7x the attention they fed at batch 64): the qkv conv's
+// NHWC output [b][token][head][d][q|k|v] with d = 64 -- a wave reads the 384 contiguous bytes of one (token, head), lane = d, and writes all three
+// operands.  Same arithmetic and reduction order as attn_pack_kernel (lane = channel, xor butterfly 32 ... 1): the same bits.
+template <typename TIN>
+__global__ __launch_bounds__(256) void attn_pack_qkv64_kernel(const TIN* __restrict__ qkv, int L, int Lkp, long tok_stride, float qscale, __bf16* __restrict__ Qp,
+                                                              __bf16* __restrict__ Kp, __bf16* __restrict__ Vt) {
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+    if (tok >= Lkp) return;
+    const bool real = tok < L;
+    float x[3] = {0.f, 0.f, 0.f};
+    if (real) {
+        const TIN* row = qkv + ((long)b * L + tok) * tok_stride + (long)h * 192 + lane * 3;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) x[w] = (float)row[w];
+    }
+    float inv[3];
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        float ss = x[w] * x[w];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+        inv[w] = 1.f / (1e-4f + sqrtf(ss) / sqrtf(64.f));
+    }
+    inv[0] *= qscale; inv[1] *= 1.f; inv[2] *= 1.f;
+    const long bh = (long)b * H + h;
+    if (real) {
+        Qp[(bh * L + tok) * 64 + lane] = (__bf16)(x[0] * inv[0]);
+        Kp[(bh * L + tok) * 64 + lane] = (__bf16)(x[1] * inv[1]);
+    }
+    const int pk = (tok & ~15) | (tok & 3) | (((tok >> 3) & 1) << 2) | (((tok >> 2) & 1) << 3);  // key order inside a group of 16 (see header)
+    Vt[(bh * 64 + lane) * Lkp + pk] = (__bf16)(x[2] * inv[2]);   // padded keys: zeros
+}
+
 #ifndef TD_ATTN_THR
 #define TD_ATTN_THR 8
 #endif
@@ -291,6 +324,13 @@ static hipError_t attn_pack(const TIN* q, const TIN* k, const TIN* v, AttnStride
     hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lq + 3) / 4, H, B), dim3(256), 0, st, q, sq, Lq, D, Dp, Dm, Lkp, 0, normalize, qscale, Qp);
     hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lk + 3) / 4, H, B), dim3(256), 0, st, k, sk, Lk, D, Dp, Dm, Lkp, 1, normalize, 1.f, Kp);
     hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lkp + 3) / 4, H, B), dim3(256), 0, st, v, sv, Lk, D, Dp, Dm, Lkp, 2, normalize, 1.f, Vt);
+    return hipGetLastError();
+}
+
+template <typename TIN>
+static hipError_t attn_pack_qkv64(const TIN* qkv, long tok_stride, int B, int H, int L, float scale, __bf16* Qp, __bf16* Kp, __bf16* Vt, hipStream_t st) {
+    const int Lkp = (L + 63) / 64 * 64;
+    hipLaunchKernelGGL(attn_pack_qkv64_kernel<TIN>, dim3((Lkp + 3) / 4, H, B), dim3(256), 0, st, qkv, L, Lkp, tok_stride, scale * 1.4426950408889634f, Qp, Kp, Vt);
     return hipGetLastError();
 }
 

@@ -223,15 +223,13 @@ __device__ __forceinline__ float pixel_rn(const float* sumsq, int nparts, size_t
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += t[u];
     }
-    if (q + 4 <= nparts) {
-        float t[4];
+    if (q < nparts) {   // the last 1 ... 7 planes in ONE round trip (round 5; they used to be four at a time and then one by one: three dependent round trips
+        float t[8];     // for the 6 planes of a 192-channel tensor); absent planes contribute an exact + 0.f (s >= 0), the order stays ascending
 #pragma unroll
-        for (int u = 0; u < 4; ++u) t[u] = b[(size_t)(q + u) * npix];
+        for (int u = 0; u < 8; ++u) t[u] = b[(size_t)(q + u < nparts ? q + u : nparts - 1) * npix];   // index-clamped: no branch around a load
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s += t[u];
-        q += 4;
+        for (int u = 0; u < 8; ++u) s += q + u < nparts ? t[u] : 0.f;
     }
-    for (; q < nparts; ++q) s += b[(size_t)q * npix];
     return 1.f / (1e-4f + sqrtf(s * inv_c));  // mp_layers.py:9-12 with dim=1: x / (eps + ||x||_c / sqrt(C))
 }
 

@@ -199,14 +199,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, TD_GLDS_MIN_WAVES(BN, WAVES
             }                                                                                          \
         }                                                                                              \
     }
-    // Round 5: the residual runs of the wide epilogue (EPI_RESIDUAL: 16 bytes per lane and unit, MT * NU units) are requested at tap 0 of the LAST
-    // 3x3 K-group into the patch-prefetch registers `av`, which are dead there -- exactly A_ITERS loads in the slot of TD_LOAD_A, so the counted
-    // waits of the tap loop hold unchanged and no register is added to the loop.  Index-clamped and unconditional (a pixel outside the image or a
+    // Round 5: the residual runs of the wide epilogue (EPI_RESIDUAL: 16 bytes per lane and unit, MT * NU units) are requested at tap 6 of the LAST
+    // 3x3 K-group into the patch-prefetch registers `av`, which are dead there -- exactly A_ITERS loads behind that tap's weight tile, with the
+    // counted waits of taps 7 and 8 (TD_TAPP); the loop carries only the run addresses (2 MT registers) on top.  Index-clamped and unconditional (a pixel outside the image or a
     // cout tile past Cout reads a valid address nobody uses).  Units beyond A_ITERS (bn 128: 8 > 6) are fetched at the top of the epilogue.
     // (never in the DMA instantiation: its launches end in 1x1 K-groups by construction)
     const bool r_want = !DMA1 && k_ks == 1 && !k_of32 && (k_Cout & 7) == 0 && k_epi == EPI_RESIDUAL && k_hres;
     bool r_pref = false;   // `av` holds the residual runs
-    int r_off[MT];
+    // Per 32-pixel row group, the address of this lane's first residual run -- made HERE, in the prologue, when the launch will prefetch: the first
+    // version read the residual's geometry (five kernel-argument fields) and did the pixel arithmetic inside tap 0 of the last K-group, and the scalar
+    // loads' lgkmcnt(0) drained the fragment reads in flight there: +2.8 k cycles in the K loop of a 27-tap workgroup, +3.2 k in the decoder's 9-tap
+    // ones (s_memtime traces, profiles/r05_conv_glds_phase_traces.txt) -- most of what the prefetch saved in the epilogue.
+    const T* r_ptr[MT];
 #define TD_R_ADDR()                                                                                                   \
     {                                                                                                                 \
         const int rHs_ = p.res_Hs, rWs_ = p.res_Ws, rrs_ = p.res_resample, rcs_ = p.res_cstride;                      \
@@ -215,16 +219,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, TD_GLDS_MIN_WAVES(BN, WAVES
             frag_pixel<TW, TPIX>(wm * WM + i_ * 32, l31, img_, ty_, tx_);                                             \
             const int n_ = n0 + img_, y_ = y0 + ty_, x_ = x0 + tx_;                                                   \
             const int sp_ = (n_ < k_N && y_ < k_H && x_ < k_W) ? src_pixel(n_, y_, x_, rHs_, rWs_, rrs_) : 0;         \
-            r_off[i_] = sp_ * rcs_ + co0 + wn * WN + 8 * lh;                                                          \
+            r_ptr[i_] = (const T*)p.res + (sp_ * rcs_ + co0 + wn * WN + 8 * lh);                                      \
         }                                                                                                             \
     }
-#define TD_R_UNIT(Q) (*(const u32x4*)((const T*)p.res + r_off[(Q) / NU] + ((co0 + wn * WN + (((Q) % NU) >> 1) * 32 < k_Cout) ? (((Q) % NU) >> 1) * 32 + ((Q) & 1) * 16 : 0)))
+#define TD_R_UNIT(Q) (*(const u32x4*)(r_ptr[(Q) / NU] + ((co0 + wn * WN + (((Q) % NU) >> 1) * 32 < k_Cout) ? (((Q) % NU) >> 1) * 32 + ((Q) & 1) * 16 : 0)))
 #define TD_LOAD_R()                                                                                                   \
     {                                                                                                                 \
-        TD_R_ADDR();                                                                                                  \
         _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) av[it_] = TD_R_UNIT(it_ < MT * NU ? it_ : MT * NU - 1); \
         r_pref = true;                                                                                                \
     }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) r_ptr[i] = nullptr;
+    if (r_want) TD_R_ADDR()
     // DMA instantiation, K range starting in a 1x1 segment (a pure 1x1 conv, or a later split-K slice): nothing is staged through registers
     const bool dma_first = DMA1 && p.seg[seg_first].taps != 9;
     if (!dma_first) {
@@ -309,19 +315,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, TD_GLDS_MIN_WAVES(BN, WAVES
         __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
         __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);                                             \
         TD_T(tA_);                                                                                           \
-        /* tile k+1 (issued one tap ago) has landed; only tap 0's patch loads may be younger (tap 1) */      \
-        if ((TAPIDX) == 1 && (has_next || r_now)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS) : "memory"); \
+        /* tile k+1 (issued one tap ago) has landed; only tap 0's patch loads may be younger (tap 1).  Last K-group of the launch (r_now): the    \
+           residual runs go out at tap 6, BEHIND the weight tile of tap 8 -- tap 7 lets them stay in flight, and tap 8 needs nothing that was    \
+           issued after that tile (tile 9 belongs to a K-group that does not exist), so nothing ever waits for them inside the loop (requested \
+           at tap 0 they had two taps to land -- patch loads hit the L2, residual rows come from HBM: +1 k cycles of tap-entry wait) */        \
+        if ((TAPIDX) == 1 && has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS) : "memory");        \
+        else if ((TAPIDX) == 7 && r_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS) : "memory");      \
+        else if ((TAPIDX) == 8 && r_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS + NBI) : "memory"); \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
         /* LDS returns in order: everything older than the two k-steps just requested is back */             \
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (NT + MT)) : "memory");                               \
         __builtin_amdgcn_s_barrier();                                                                        \
         asm volatile("" ::: "memory");                                                                       \
         TD_T(tB_); TD_TACC(tr_wait, tA_, tB_);                                                               \
-        if ((TAPIDX) == 3 && (has_next || r_now)) {                                                          \
+        if ((TAPIDX) == 3 && has_next) {                                                                     \
             _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) asm volatile("" : "+v"(av[it_]));      \
         }                                                                                                    \
         TD_ABL_BLOAD(TD_GLDS_B(((SLOT) + 2) % RING));                                                        \
-        if ((TAPIDX) == 0) { if (has_next) TD_LOAD_A(chunk + 1) else if (r_now) TD_LOAD_R() }                \
+        if ((TAPIDX) == 0 && has_next) TD_LOAD_A(chunk + 1);                                                 \
+        if ((TAPIDX) == 6 && r_now) TD_LOAD_R()                                                              \
         TD_FRAG_MFMA(wfA_, xfA_);                                                                            \
         if ((TAPIDX) < 8) TD_FRAG_READ(wfA_, xfA_, ((SLOT) + 1) % RING, 0, TOFF_NEXT);                       \
         TD_FRAG_MFMA(wfB_, xfB_);                                                                            \
@@ -565,8 +577,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, TD_GLDS_MIN_WAVES(BN, WAVES
 #pragma unroll
     for (int q = 0; q < NRX; ++q) rx[q] = u32x4{0u, 0u, 0u, 0u};
     if (wide && has_res) {
+        if (!r_want) TD_R_ADDR()   // (the DMA instantiation, split-K: no prefetch was planned, the addresses are made here)
         if (!r_pref) TD_LOAD_R()   // the launch ended in 1x1 K-groups (attention projection): nothing was requested yet
-        else if (MT * NU > A_ITERS) TD_R_ADDR()
         if constexpr (MT * NU > A_ITERS) {
 #pragma unroll
             for (int q = 0; q < NRX; ++q) rx[q] = TD_R_UNIT(A_ITERS + q);

@@ -228,7 +228,13 @@ __global__ __launch_bounds__(256, 2) void conv_sb_kernel(const ConvParams p) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) s += t[u];
                 }
-                for (; q < rn_parts; ++q) s += sp[(size_t)q * npix];
+                if (q < rn_parts) {   // the last 1 ... 7 planes in one round trip (pixel_rn of conv_common.h)
+                    float t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = sp[(size_t)(q + u < rn_parts ? q + u : rn_parts - 1) * npix];   // index-clamped: no branch around a load
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += q + u < rn_parts ? t[u] : 0.f;
+                }
                 rn = 1.f / (1e-4f + sqrtf(s * rn_invc));   // mp_layers.py:9-12 with dim=1 (pixel_rn of conv_common.h)
             }
             s_rn[pp] = rn;
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void conv_sb_kernel(const ConvParams p) {
     // ---------------- 1x1 K-groups: both operands straight from global memory, no LDS and no barrier; batches of D1 groups (a batch's loads
     // are requested while the previous batch is contracted; whole 1x1 phases of <= D1 groups -- most of them -- are one request burst)
     if (a1 < ngroups) {
-        constexpr int D1 = 8;
+        constexpr int D1 = MT >= 4 ? 4 : 8;   // (the 128-pixel tile holds four B fragments per group: half the depth for the same registers)
         int sg1 = 0;
         while (sg1 < p.nseg && p.seg[sg1].taps == 9) ++sg1;   // first 1x1 segment
         u32x4 wa[D1][NT], xa[D1][MT];
@@ -515,11 +521,14 @@ static hipError_t launch_sb_cfg(const ConvParams& p, hipStream_t st) {
     return e;
 }
 
-// Tile configurations: mt = 32-pixel MFMA blocks per workgroup (2: 4x16 or 8x8 pixels, 1: 2x16 or 4x8), nt = 32-cout blocks (1 or 2).
+// Tile configurations: mt = 32-pixel MFMA blocks per workgroup (4: 8x16 pixels, 16-wide maps and nt = 1 only; 2: 4x16 or 8x8 pixels, 1: 2x16 or 4x8),
+// nt = 32-cout blocks (1 or 2).  Round 5, the 128 px x 32 cout tile: the K loop is bound by what one CU can ingest, and per K-group this tile ingests
+// 36.9 KB of weights + 23 KB of patch = 60 KB against the 87.5 KB of the 64 x 64 tile with the SAME number of workgroups and MFMAs per wave.
 // The caller sets tiles_x / tiles_y for that tile, img_groups = N, n_ntiles = CoutPad / (32 nt), ksplit (+ kb[], partial when > 1).
 template <typename T>
 static hipError_t launch_conv_sb_t(const ConvParams& p, bool narrow, int mt, int nt, hipStream_t st) {
     if (!narrow) {
+        if (mt == 4) return nt == 1 ? launch_sb_cfg<T, 8, 16, 1>(p, st) : hipErrorInvalidValue;   // round 5: 128 px x 32 couts
         if (mt == 2) return nt == 2 ? launch_sb_cfg<T, 4, 16, 2>(p, st) : launch_sb_cfg<T, 4, 16, 1>(p, st);
         return nt == 2 ? launch_sb_cfg<T, 2, 16, 2>(p, st) : launch_sb_cfg<T, 2, 16, 1>(p, st);
     }
@@ -529,7 +538,7 @@ static hipError_t launch_conv_sb_t(const ConvParams& p, bool narrow, int mt, int
 
 // dtype: 1 bf16, 2 fp16 (this flavour has no fp32 form)
 hipError_t launch_conv_sb(const ConvParams& p, int dtype, bool narrow, int mt, int nt, hipStream_t st) {
-    if ((mt != 1 && mt != 2) || (nt != 1 && nt != 2)) return hipErrorInvalidValue;
+    if ((mt != 1 && mt != 2 && !(mt == 4 && nt == 1 && !narrow)) || (nt != 1 && nt != 2)) return hipErrorInvalidValue;
     return dtype == 2 ? launch_conv_sb_t<_Float16>(p, narrow, mt, nt, st) : launch_conv_sb_t<__bf16>(p, narrow, mt, nt, st);
 }
 

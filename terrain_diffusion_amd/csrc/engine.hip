@@ -664,7 +664,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
     static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn",
                                                "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
                                                "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups", "glds_round_aware", "walk_alternate", "glds_tiny", "glds_dma1x1", "splitk_weighted",
-                                               "sb", "sb_target_wgs", "sb_mt", "sb_nt", "sb_order", "sb_max_glds_wgs", "sb_splitk", "sb_splitk_wgs", "sb_splitk_max", "s16", "s16_min_wgs"};
+                                               "sb", "sb_target_wgs", "sb_mt", "sb_nt", "sb_order", "sb_max_glds_wgs", "sb_splitk", "sb_splitk_wgs", "sb_splitk_max", "s16", "s16_min_wgs", "sb_m4"};
     std::string key = std::to_string(N) + "_" + std::to_string(H) + "_" + std::to_string(W);
     for (const char* o : kPlanOptions) key += "_" + std::to_string((long long)u->eng->option(o, -7));
     if (lane) key += "_lane" + std::to_string(lane);   // a second, independent activation set of the same shape (concurrent half-batches)
@@ -820,18 +820,22 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                 if (op.flavor == 2 && sb_takes) {
                     {
                         const int TWs = op.narrow ? 8 : 16;
-                        auto th_of = [&](int mt) { return op.narrow ? (mt == 2 ? 8 : 4) : (mt == 2 ? 4 : 2); };
+                        auto th_of = [&](int mt) { return op.narrow ? (mt == 2 ? 8 : 4) : (mt == 4 ? 8 : mt == 2 ? 4 : 2); };
                         auto sb_wgs = [&](int mt, int nt) { return (int64_t)((w + TWs - 1) / TWs) * ((h + th_of(mt) - 1) / th_of(mt)) * N * (cw.cout_pad / (32 * nt)); };
                         const int64_t target = u->eng->option("sb_target_wgs", 160);
                         int mt = 1, nt = 1, ks = 1;
-                        if (sb_wgs(2, 2) >= target) { mt = 2; nt = 2; } else if (sb_wgs(2, 1) >= target) { mt = 2; nt = 1; }
+                        // round 5: where 64 x 64 would be chosen and 128 px x 32 couts gives as many workgroups (16-wide maps: the 64x64 level of one or two
+                        // tiles, the 32x32 level of small batches), the latter: 31 % fewer bytes per workgroup and K-group on a loop bound by what a CU ingests
+                        if (!op.narrow && u->eng->option("sb_m4", 1) != 0 && sb_wgs(2, 2) >= target && sb_wgs(4, 1) >= target) { mt = 4; nt = 1; }
+                        else if (sb_wgs(2, 2) >= target) { mt = 2; nt = 2; } else if (sb_wgs(2, 1) >= target) { mt = 2; nt = 1; }
                         else if (use_splitk && u->eng->option("sb_splitk", 1) != 0 && sb_wgs(2, 1) * 2 <= u->eng->option("sb_splitk_wgs", 224)) {
                             mt = 2; nt = 1;
                             ks = (int)std::min<int64_t>(std::min<int64_t>(kgroups, u->eng->option("sb_splitk_max", 16)), (u->eng->option("sb_splitk_wgs", 224) + sb_wgs(2, 1) / 2) / sb_wgs(2, 1));
                         }
                         const int64_t fmt = u->eng->option("sb_mt", 0), fnt = u->eng->option("sb_nt", 0);   // test hooks
-                        if (fmt == 1 || fmt == 2) { mt = (int)fmt; ks = 1; }
-                        if (fnt == 1 || fnt == 2) { nt = (int)fnt; ks = 1; }
+                        if (fmt == 1 || fmt == 2 || (fmt == 4 && !op.narrow)) { mt = (int)fmt; ks = 1; }
+                        if (fnt == 1 || fnt == 2) { nt = (int)fnt; ks = 1; if (mt == 4 && fnt == 2 && fmt != 4) mt = 2; }
+                        if (mt == 4) nt = 1;   // (the 128-pixel tile exists with 32 couts only)
                         // Round 5: the launches that would split K over workgroups on top (the weight-streaming-bound 8x8 / 16x16 levels of one or
                         // two tiles) take the deep-level latency flavour instead (conv_s16.hip: 64 px x 16 couts, twice the workgroups per weight
                         // byte, no partial planes, no reduce launch).  Option "s16": 1 = there (default), 0 = never, 2 = wherever conv_sb applies (test hook).
@@ -1122,8 +1126,8 @@ static int run_unet(td_unet* u, Plan& pl, int step, const SchedCoef* fuse = null
                 attn_workspace_elems(pl.N, Hh, L, L, 64, &qn, &kn, &vn);
                 __bf16 *Qp = (__bf16*)op.attn_ws, *Kp = Qp + qn, *Vt = Kp + kn;
                 const __bf16* qkv = (const __bf16*)op.qkv;
-                const AttnStrides si = {(long)L * 3 * op.C, 64L * 3, 3L * op.C, 3L}, so = {(long)L * op.C, 64L, (long)op.C, 1L};
-                hipError_t ea = attn_pack<__bf16>(qkv, qkv + 1, qkv + 2, si, si, si, pl.N, Hh, L, L, 64, 1, 0.125f, Qp, Kp, Vt, st);
+                const AttnStrides so = {(long)L * op.C, 64L, (long)op.C, 1L};   // (input: element (b, token, head, d, q|k|v) of the qkv conv's NHWC output)
+                hipError_t ea = attn_pack_qkv64<__bf16>(qkv, 3L * op.C, pl.N, Hh, L, 0.125f, Qp, Kp, Vt, st);   // one launch for q, k and v (the generic attn_pack: td_attention)
                 if (ea == hipSuccess) ea = attn_mfma(Qp, Kp, Vt, nullptr, (__bf16*)op.att, so, pl.N, Hh, L, L, 64, st);
                 if (ea != hipSuccess) return fail(TD_ERR_HIP, std::string("attention launch: ") + hipGetErrorString(ea));
             } else
@@ -1150,7 +1154,7 @@ static int run_unet(td_unet* u, Plan& pl, int step, const SchedCoef* fuse = null
             const double mbs_ = (mb_ + o1_) * 1e-6;   /* strict: without the optional pre-activated second output (an optimisation, not part of the layer's definition) */
             mb_ += o1_ * (p.out2 ? 2.0 : 1.0);
             mb_ *= 1e-6;
-            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f mb%.2f mbs%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 5 ? "c16" : op.flavor == 4 ? (op.sb_mt == 2 ? (op.sb_nt == 2 ? "m2n2" : "m2n1") : (op.sb_nt == 2 ? "m1n2" : "m1n1")) : op.flavor == 2 ? (op.glds_variant == 2 ? "t" : op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_, mb_, mbs_); ev_label.push_back(op.label + tag);
+            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f mb%.2f mbs%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 5 ? "c16" : op.flavor == 4 ? (op.sb_mt == 4 ? "m4n1" : op.sb_mt == 2 ? (op.sb_nt == 2 ? "m2n2" : "m2n1") : (op.sb_nt == 2 ? "m1n2" : "m1n1")) : op.flavor == 2 ? (op.glds_variant == 2 ? "t" : op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_, mb_, mbs_); ev_label.push_back(op.label + tag);
             ev_flop.push_back(op.flavor == 2 ? 2.0 * p.N * p.H * p.W * (double)p.Cout * op.k_alg : 0.0); }   // the LDS-DMA family alone (bench.py's roofline kernel); small-batch launches are told apart by their f4 label
         if (e != hipSuccess) return fail(TD_ERR_HIP, "conv launch " + op.label + ": " + hipGetErrorString(e));
     }
@@ -1217,7 +1221,7 @@ static const char* const kKnownOptions[] = {
     // plan builder (speed only, or test hooks that force a tile shape; all part of the plan-cache key)
     "attn_mfma", "bn128_min_wgs", "glds", "glds_bn", "glds_bn64", "glds_dma1x1", "glds_min_wgs", "glds_round_aware", "glds_small_max_groups",
     "glds_splitk", "glds_splitk_from_groups", "glds_splitk_max", "glds_splitk_min_groups", "glds_tiny", "glds_variant",
-    "producer_act", "s16", "s16_min_wgs", "sb", "sb_max_glds_wgs", "sb_mt", "sb_nt", "sb_order", "sb_splitk", "sb_splitk_max", "sb_splitk_wgs", "sb_target_wgs", "splitk",
+    "producer_act", "s16", "s16_min_wgs", "sb", "sb_m4", "sb_max_glds_wgs", "sb_mt", "sb_nt", "sb_order", "sb_splitk", "sb_splitk_max", "sb_splitk_wgs", "sb_target_wgs", "splitk",
     "splitk_target_wgs", "splitk_weighted", "walk_alternate"};
 int td_engine_set_option(td_engine* e, const char* key, int64_t value) {
     if (!e || !key) return fail(TD_ERR_ARG, "null");

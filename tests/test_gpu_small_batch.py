@@ -75,7 +75,7 @@ def test_single_tile_forward_runs_on_the_small_batch_flavour_and_matches_the_ref
     assert rel_rms(y.cpu().numpy(), y0.cpu().numpy()) < tol
 
 
-@pytest.mark.parametrize("mt,nt", [(2, 2), (2, 1), (1, 2), (1, 1)])
+@pytest.mark.parametrize("mt,nt", [(2, 2), (2, 1), (1, 2), (1, 1), (4, 1)])
 def test_every_tile_shape_of_the_small_batch_flavour(td, orc, golden, base, mt, nt):
     """test hooks sb_mt / sb_nt force one tile shape on every layer (64 / 32 pixels x 64 / 32 couts, 16-wide and 8-wide maps): each must hold
     the reference bound on its own"""
@@ -89,7 +89,8 @@ def test_every_tile_shape_of_the_small_batch_flavour(td, orc, golden, base, mt, 
     finally:
         eng.set_option("sb_mt", 0); eng.set_option("sb_nt", 0)
     tag = f"f4m{mt}n{nt}"
-    assert sum(v == tag for v in fl.values()) >= 70, fl
+    # (the 128-pixel tile of round 5 exists on 16-wide maps only: the 8x8 level keeps the planner's tile there)
+    assert sum(v == tag for v in fl.values()) >= (50 if mt == 4 else 70), fl
     err = rel_rms(y.cpu().numpy(), golden("unet")["base_out"])
     print(f"sb tile m{mt} n{nt}: rel-RMS vs reference {err:.3e}")
     assert err < 2e-2
@@ -119,7 +120,8 @@ def test_deep_level_flavour_everywhere_and_no_reduce_launch_in_a_single_tile_for
     args = _inputs(orc, 1)
     m = base[dtype]
     sk = _split_k_launches(eng, m, args)
-    assert 0 < len(sk) <= 26 and all("8x8" in l for l in sk), sk
+    # (the two 384-cout convs of the 16x16 level's down block give 96 workgroups of 16 couts: below "s16_min_wgs", they keep their split-K plan too)
+    assert 0 < len(sk) <= 26 and all("8x8" in l or "128x128_down" in l for l in sk), sk
     try:
         eng.set_option("s16", 2)
         y = m(*args)

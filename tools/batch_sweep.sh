@@ -33,7 +33,7 @@ for n in map(int, sys.argv[1:]):
 with open(R + "/gpurun_out/batch_sweep.txt", "w") as o:
     o.write("base U-Net (30m config) forward vs batch, bf16, MI355X.  wall = ms per forward inside the captured 20-step sampler graph (bench.py --workload tiles);\n"
             "kernel = sum of per-launch HIP-event times in eager profile mode; TF/s = batch x 193.654 GFLOP / wall; HBM MB per forward = rocprofv3 --pmc FETCH_SIZE x 2 / WRITE_SIZE\n"
-            "(weights alone: 507 MB); plan = conv launches by flavour (f4 = small-batch conv_sb m<px/32>n<cout/32>, f2 = conv_glds big/small tile, f0 = per-tap)\n\n")
+            "(weights alone: 507 MB); plan = conv launches by flavour (f5c16 = conv_s16 64 px x 16 couts, f4 = small-batch conv_sb m<px/32>n<cout/32>, f2 = conv_glds big/small tile, f0 = per-tap)\n\n")
     o.write(f"{'batch':>5} {'wall ms':>9} {'kernel ms':>10} {'TF/s':>8} {'read MB':>9} {'write MB':>9}  plan\n")
     for n, w, k, tf, rd, wr, fl in rows:
         o.write(f"{n:>5} {w:>9.3f} {k:>10.3f} {tf:>8.1f} {rd:>9.0f} {wr:>9.0f}  {' '.join(f'{a}:{b}' for a, b in sorted(fl.items()))}\n")

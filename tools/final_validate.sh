@@ -14,5 +14,4 @@ TD_TOP=90 timeout 120 python tools/profile_ops.py 1 bf16 > gpurun_out/final_per_
 timeout 600 python -c "from terrain_diffusion_amd.latency import measure_latency as m; import json; print(json.dumps(m(num_runs=60, dtype='bf16')))" 2>/dev/null | tail -1 > gpurun_out/final_ttft_ttst.json
 timeout 300 bash tools/b1_timeline.sh > gpurun_out/final_b1_timeline.log 2>&1
 timeout 600 bash tools/sb_layers.sh > gpurun_out/final_sb_layers.txt 2>&1
-timeout 300 bash tools/sb_trace.sh > gpurun_out/final_sb_trace.txt 2>&1
 tail -4 gpurun_out/final_tests.txt; tail -2 gpurun_out/final_smoke.txt; cut -c1-700 gpurun_out/final_bench_grid8.json; cut -c1-300 gpurun_out/final_bench_cascade.json

@@ -85,7 +85,7 @@ int main(int argc, char** argv) {
     CK(launch_conv(pr, 1, narrow, 64, 0, st));
     // ---- sb
     ConvParams ps = p; ps.out = out; ps.out_sumsq = ssq; ps.out2 = o2; ps.wpack_sb = wsb; ps.sb_n3 = n3; ps.sb_order = order;
-    { const int TW = narrow ? 8 : 16, TH = narrow ? ((mt == 2 || s16) ? 8 : 4) : ((mt == 2 || s16) ? 4 : 2); ps.tiles_x = (W + TW - 1) / TW; ps.tiles_y = (H + TH - 1) / TH; ps.img_groups = N; ps.n_ntiles = s16 ? CoutPad / 16 : CoutPad / (32 * nt); }
+    { const int TW = narrow ? 8 : 16, TH = narrow ? ((mt == 2 || s16) ? 8 : 4) : (mt == 4 ? 8 : (mt == 2 || s16) ? 4 : 2); ps.tiles_x = (W + TW - 1) / TW; ps.tiles_y = (H + TH - 1) / TH; ps.img_groups = N; ps.n_ntiles = s16 ? CoutPad / 16 : CoutPad / (32 * nt); }
     auto LSB = [&](const ConvParams& q_) { return s16 ? launch_conv_s16(q_, 1, narrow, st) : launch_conv_sb(q_, 1, narrow, mt, nt, st); };
     const int sb_ks = A(15, 1);   // split-K over workgroups on top of the in-workgroup split (+ reduce launch)
     if (sb_ks > 1) {

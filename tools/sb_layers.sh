@@ -22,6 +22,12 @@ run 1 16 16 576 576 1 1 0 1 2 $O 0 9
 run 1 16 16 576 576 2 1 0 1 2 $O 0 9
 run 1 16 16 1152 576 1 1 0 1 0 $O 0 18
 run 1 16 16 576 576 1 1 1152 2 0 $O 0 27
+echo "== level C 16x16, the 64 px x 16 cout flavour (conv_s16.hip: mt 0)"
+run 1 16 16 576 576 0 0 0 1 2 $O 0 9
+run 1 16 16 576 576 0 0 0 2 0 $O 0 9 1
+run 1 16 16 1152 576 0 0 0 1 0 $O 0 18
+run 1 16 16 576 576 0 0 1152 2 0 $O 0 27
+run 1 16 16 384 576 0 0 0 1 0 $O 2 6
 echo "== level D 8x8"
 run 1 8 8 768 768 2 1 0 1 2 $O 0 12
 run 1 8 8 768 768 1 1 0 1 2 $O 0 12
@@ -29,6 +35,8 @@ run 1 8 8 1536 768 2 1 0 1 0 $O 0 24
 run 1 8 8 768 768 2 1 1536 2 0 $O 0 32
 run 1 8 8 0 2304 2 1 768 0 0 $O 0 12
 run 1 8 8 0 768 2 1 768 2 0 $O 0 12
+run 1 8 8 768 768 0 0 0 1 2 $O 0 12
+run 1 8 8 768 768 0 0 1536 2 0 $O 0 32
 echo "== batches"
 run 4 32 32 384 384 2 2 0 1 2 $O 0 2
 run 4 16 16 576 576 2 1 0 1 2 $O 0 4
@@ -37,3 +45,5 @@ run 16 16 16 576 576 2 2 0 1 2 $O 0 1
 run 16 8 8 768 768 2 2 0 1 2 $O 0 4
 run 3 40 40 192 192 2 2 0 2 0 $O 0 0 1
 run 2 24 24 128 320 1 1 64 2 0 $O 0 0
+run 2 24 24 128 320 0 0 64 2 0 $O 0 0
+run 3 9 9 256 192 0 0 0 2 0 $O 0 0 1
