@@ -25,13 +25,11 @@ namespace td {
 #endif
 
 // DMA1: the instantiation that streams 1x1 segments by LDS-DMA (launch_glds_cfg picks it per launch; the plain instantiation is untouched by it)
-#ifdef TD_BN64_OCC3   // experiment (tools/conv_bench.hip): three 4-wave workgroups of the 64-cout tile per CU (<= 168 VGPRs, 51.5 KB of LDS each)
-#define TD_GLDS_MIN_WAVES(BN, W) ((BN) == 64 && (W) == 4 ? 3 : ((W) + 3) / 4 < 2 ? 2 : ((W) + 3) / 4)
-#else
-#define TD_GLDS_MIN_WAVES(BN, W) (((W) + 3) / 4 < 2 ? 2 : ((W) + 3) / 4)
-#endif
+// (two workgroups of a 4-wave tile per CU.  Three of the 64-cout tile fit the LDS and, at 168 VGPRs, cost 40 bytes of scratch per lane: measured 17 % SLOWER on the
+// decoder's 64 -> 64 layers, level on 128 / 192 -> 64 -- profiles/r05_decoder_512_level_experiments.txt)
+#define TD_GLDS_MIN_WAVES(BN, W, DMA) (((W) + 3) / 4 < 2 ? 2 : ((W) + 3) / 4)
 template <typename T, int TH, int TW, int NIMG, int BN, int WAVES_M, int WAVES_N, bool DMA1 = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, TD_GLDS_MIN_WAVES(BN, WAVES_M * WAVES_N)) void conv_glds_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, TD_GLDS_MIN_WAVES(BN, WAVES_M * WAVES_N, DMA1)) void conv_glds_kernel(const ConvParams p) {
     typedef typename Half<T>::x8 hx8;
     typedef typename Half<T>::x4 hx4;
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
@@ -170,7 +168,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, TD_GLDS_MIN_WAVES(BN, WAVES
         seg_src = (const T*)sg_.src; seg_taps = sg_.taps; seg_xform = sg_.xform; seg_scale = sg_.scale; seg_nchunks = sg_.C / CHUNK; \
         const int Hs_ = sg_.Hs, Ws_ = sg_.Ws, rs_ = sg_.resample, cs_ = sg_.cstride;                                  \
         _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) {                                                   \
-            const int c_ = a_coord[it_];                                                                              \
+            int c_ = a_coord[it_];                                                                                    \
+            /* opaque: hipcc otherwise decodes (n, y, x) of every piece ONCE, in front of the segment loop, and keeps the 18 values alive across \
+               the K loop -- in scratch (bn 128: 72 bytes per lane written and read back per workgroup = ~30 MB of traffic per launch) */       \
+            asm volatile("" : "+v"(c_));                                                                              \
             aoff[it_] = -1;                                                                                           \
             if (c_ >= 0 && (seg_taps == 9 || (c_ & 1)))                                                               \
                 aoff[it_] = src_pixel(c_ >> 21, (c_ >> 11) & 1023, (c_ >> 1) & 1023, Hs_, Ws_, rs_) * cs_ + (tid & 7) * PER16; \
@@ -275,6 +276,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, TD_GLDS_MIN_WAVES(BN, WAVES
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wbase[ks] = (unsigned)(nl * 128 + (((ks * 2 + lh) ^ TD_SWZ(nl)) << 4));
     }
+    __syncthreads();  // s_rn visible (prologue only: this one may drain the two weight tiles, they are needed next anyway)
+    if (!dma_first) TD_STORE_A();
+    // (zeroed HERE, behind the prologue: zeroed in front of it the 32-64 accumulator registers were live across the patch-address arithmetic and the
+    // 1/rms table, and the bn 128 instantiations spilled 18-22 dwords per lane there -- ~35 MB of scratch written and read back per launch)
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -282,9 +287,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, TD_GLDS_MIN_WAVES(BN, WAVES
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    __syncthreads();  // s_rn visible (prologue only: this one may drain the two weight tiles, they are needed next anyway)
-    if (!dma_first) TD_STORE_A();
     TD_T(tr_pro);
 
 #define TD_TOFF(T) ((((T) / 3) * PW + ((T) % 3)) * PITCH)

@@ -403,7 +403,9 @@ class DeviceWindowTensor(InfiniteTensor):
             for k, c in enumerate(p_):
                 desc[r, k] = (order[c], c[1] * self.stride_hw + oy - b[1][0], c[2] * self.stride_hw + ox - b[2][0])
         # the window tensors stay alive until the call returns; when the engine only enqueues (Engine.on_stream) they may be released earlier, which
-        # is safe in stream order: the allocator hands their memory to later work of the same stream only
+        # is safe in stream order: the allocator hands their memory to later work of the same stream only.  That rests on ONE stream producing and
+        # consuming them (torch's current stream = the engine's stream inside on_stream; the engine's own stream with synchronous calls otherwise):
+        # a caller that reads these tensors on another stream must order that stream itself (tensor.record_stream / wait_stream), as with any torch tensor
         keep = list(tiles.values())
         ptrs = np.asarray([t.data_ptr() for t in keep], dtype=np.uint64)
         out = torch.empty((n, self.channels + 1, h, w), dtype=torch.float32, device=self.device)
