@@ -112,7 +112,7 @@ def run_cascade(args, eng, dev, rank, world):
     import re
     by_level, mb_level = {}, {}
     for label, ms, n in ops:
-        mres = re.search(r"\[(\d+x\d+) .* mb([0-9.]+)\]", label)
+        mres = re.search(r"\[(\d+x\d+) .* mb([0-9.]+)(?: mbs[0-9.]+)?\]", label)   # (round 5: the label also carries the strict figure, without the second output)
         if mres:
             a = mb_level.setdefault(mres.group(1), [0.0, 0.0])
             a[0] += float(mres.group(2)) * n; a[1] += ms
