@@ -88,7 +88,7 @@ int td_engine_set_stream(td_engine* e, void* hip_stream);
  *   "glds", "glds_min_wgs", "glds_bn64", "glds_round_aware", "glds_small_max_groups", "glds_dma1x1", "glds_tiny", "bn128_min_wgs",
  *   "splitk", "splitk_target_wgs", "splitk_weighted", "glds_splitk", "glds_splitk_from_groups", "glds_splitk_max", "glds_splitk_min_groups",
  *   "producer_act", "walk_alternate", "attn_mfma",
- *   "sb" (small-batch conv flavour), "sb_m4" (its 128 px x 32 cout tile), "sb_target_wgs", "sb_order", "sb_max_glds_wgs", "sb_splitk", "sb_splitk_wgs", "sb_splitk_max",
+ *   "sb" (small-batch conv flavour), "sb_m4"=0/1 (its 128 px x 32 cout tile, off by default), "sb_target_wgs", "sb_order", "sb_max_glds_wgs", "sb_splitk", "sb_splitk_wgs", "sb_splitk_max",
  *   "s16"=0/1/2 (deep-level latency flavour, conv_s16.hip: never / where conv_sb would split K over workgroups and the 16-cout grid reaches
  *   "s16_min_wgs" workgroups / wherever conv_sb applies).
  * Test hooks that force a tile shape wherever it is legal: "glds_variant"=-1/0/1, "glds_bn"=0/64/96/128, "sb_mt"=0/1/2/4, "sb_nt"=0/1/2. */

@@ -824,9 +824,10 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                         auto sb_wgs = [&](int mt, int nt) { return (int64_t)((w + TWs - 1) / TWs) * ((h + th_of(mt) - 1) / th_of(mt)) * N * (cw.cout_pad / (32 * nt)); };
                         const int64_t target = u->eng->option("sb_target_wgs", 160);
                         int mt = 1, nt = 1, ks = 1;
-                        // round 5: where 64 x 64 would be chosen and 128 px x 32 couts gives as many workgroups (16-wide maps: the 64x64 level of one or two
-                        // tiles, the 32x32 level of small batches), the latter: 31 % fewer bytes per workgroup and K-group on a loop bound by what a CU ingests
-                        if (!op.narrow && u->eng->option("sb_m4", 1) != 0 && sb_wgs(2, 2) >= target && sb_wgs(4, 1) >= target) { mt = 4; nt = 1; }
+                        // round 5: a 128 px x 32 cout tile exists for the launches where 64 x 64 would be chosen and it gives as many workgroups (31 % fewer
+                        // ingested bytes per workgroup and K-group).  OFF by default (option sb_m4 = 1 takes it): measured level -- -0.3 % / -1 % of a forward at
+                        // batch 1 / 2, +2.5 % at batch 8, +1 % at 16, -1 % at 32 (profiles/r05_conv_sb_128px_tile.txt)
+                        if (!op.narrow && u->eng->option("sb_m4", 0) != 0 && sb_wgs(2, 2) >= target && sb_wgs(4, 1) >= target) { mt = 4; nt = 1; }
                         else if (sb_wgs(2, 2) >= target) { mt = 2; nt = 2; } else if (sb_wgs(2, 1) >= target) { mt = 2; nt = 1; }
                         else if (use_splitk && u->eng->option("sb_splitk", 1) != 0 && sb_wgs(2, 1) * 2 <= u->eng->option("sb_splitk_wgs", 224)) {
                             mt = 2; nt = 1;
@@ -1082,6 +1083,18 @@ static int compute_cvecs(td_unet* u, Plan& pl, const std::vector<float>& t_steps
     int max_cout = 64;
     for (auto& b : u->enc) max_cout = std::max(max_cout, b.cout);
     for (auto& b : u->dec) max_cout = std::max(max_cout, b.cout);
+    bool c16 = u->emb_ch % 16 == 0 && u->c_total % 4 == 0;   // the matrix-core form needs 16-byte operand pieces and whole 16-cout slices
+    for (auto& b : u->enc) c16 = c16 && b.cout % 16 == 0;
+    for (auto& b : u->dec) c16 = c16 && b.cout % 16 == 0;
+    if (c16 && u->emb_ch % 64 == 0)
+        hipLaunchKernelGGL(cvec_mfma_kernel<4>, dim3((max_cout + 63) / 64, (rows + 63) / 64, u->n_blocks), dim3(256), 0, st, (const float*)pl.emb->p, rows,
+                           u->emb_ch, (const float*)u->d_wemb->p, (const int*)u->d_blk_woff->p, (const int*)u->d_blk_coff->p, (const int*)u->d_blk_cout->p,
+                           u->c_total, (float*)pl.cvec->p);
+    else if (c16)
+        hipLaunchKernelGGL(cvec_mfma_kernel<1>, dim3((max_cout + 63) / 64, (rows + 63) / 64, u->n_blocks), dim3(256), 0, st, (const float*)pl.emb->p, rows,
+                           u->emb_ch, (const float*)u->d_wemb->p, (const int*)u->d_blk_woff->p, (const int*)u->d_blk_coff->p, (const int*)u->d_blk_cout->p,
+                           u->c_total, (float*)pl.cvec->p);
+    else
     hipLaunchKernelGGL(cvec_kernel, dim3((max_cout + 63) / 64, (rows + 15) / 16, u->n_blocks), dim3(256), (size_t)16 * u->emb_ch * 4, st, (const float*)pl.emb->p, rows,
                        u->emb_ch, (const float*)u->d_wemb->p, (const int*)u->d_blk_woff->p, (const int*)u->d_blk_coff->p, (const int*)u->d_blk_cout->p,
                        u->c_total, (float*)pl.cvec->p);

@@ -102,6 +102,70 @@ __global__ __launch_bounds__(256) void cvec_kernel(const float* __restrict__ emb
     }
 }
 
+// The same product on the fp32 matrix cores (round 5): at the bench batch the scalar kernel above took 4.2 ms per sampler call (1280 rows x 14 k couts x 768:
+// 27.5 GFLOP at 6.5 TFLOP/s -- 1.5 % of a configs[2] step for 0.01 % of its arithmetic), at batch 1 147 us (43 MB of weights at 290 GB/s).  Exact fp32 FMA
+// chains (v_mfma_f32_16x16x4_f32); only the association of the 768 products of an output differs from the scalar kernel (a tree over lanes there, four
+// interleaved chains here): ~1e-7 relative, far inside the fp32 mode's 5e-6.
+// D[cout][row] = W[cout][k] E[row][k]: A operand = W (row = cout lane & 15), B operand = E (column = row lane & 15); the contraction index is taken in
+// the order that makes every operand load a 16-byte piece: lane group g = lane >> 4 of super-step m holds k = 16 m + 4 g ... + 3, MFMA t of the
+// super-step contracts {16 m + 4 g + t : g = 0..3} (any partition of K into fours is as good as any other as long as both operands agree).
+// A wave: 16 couts x 64 rows (one A piece, four B pieces, 16 MFMAs per super-step, everything straight from global memory / L2: the four waves of a
+// workgroup take four cout slices of the same 64 rows).  grid (cout tiles of 64, row tiles of 64, block index).
+// U super-steps (16 U channels) are requested at a time, one block ahead of the MFMAs that use them: at batch 1 a wave streams its 48 KB of weights with
+// 5 U KiB in flight (the single-tile call is bound by that stream: 43 MB of fp32 weights for 20 rows).  emb_ch % (16 U) == 0.
+template <int U>
+__global__ __launch_bounds__(256) void cvec_mfma_kernel(const float* __restrict__ emb, int rows, int emb_ch, const float* __restrict__ w_all,
+                                                        const int* __restrict__ blk_woff, const int* __restrict__ blk_coff,
+                                                        const int* __restrict__ blk_cout, int c_total, float* __restrict__ craw) {
+    const int blk = blockIdx.z, cout = blk_cout[blk];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int co0 = blockIdx.x * 64 + wave * 16;
+    if (co0 >= cout) return;   // (couts are multiples of 16: a 16-cout slice is inside the block or outside it)
+    const int r0 = blockIdx.y * 64;
+    const float* wrow = w_all + blk_woff[blk] + (size_t)(co0 + li) * emb_ch + 4 * lg;
+    const float* erow[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) { const int r = r0 + nb * 16 + li; erow[nb] = emb + (size_t)(r < rows ? r : rows - 1) * emb_ch + 4 * lg; }
+    f32x4 acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 a_next[U], b_next[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        a_next[u] = *(const f32x4*)(wrow + 16 * u);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) b_next[u][nb] = *(const f32x4*)(erow[nb] + 16 * u);
+    }
+    for (int k = 0; k < emb_ch; k += 16 * U) {
+        f32x4 a[U], b[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a[u] = a_next[u];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) b[u][nb] = b_next[u][nb];
+        }
+        const int kn = k + 16 * U < emb_ch ? k + 16 * U : k;   // (the last block re-reads itself: the loads stay unconditional)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a_next[u] = *(const f32x4*)(wrow + kn + 16 * u);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) b_next[u][nb] = *(const f32x4*)(erow[nb] + kn + 16 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], b[u][nb][t], acc[nb], 0, 0, 0);
+    }
+    // D: row (cout) 4 (lane >> 4) + r, column (row of c) lane & 15: four consecutive couts of one row per lane
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int r = r0 + nb * 16 + li;
+        if (r < rows) *(f32x4*)(craw + (size_t)r * c_total + blk_coff[blk] + co0 + 4 * lg) = acc[nb] + 1.f;
+    }
+}
+
 // c /= sqrt(mean(c^2) + 1e-8) per (row, block).  grid (rows, blocks)
 __global__ __launch_bounds__(256) void cvec_norm_kernel(float* __restrict__ c, const int* __restrict__ blk_coff, const int* __restrict__ blk_cout, int c_total) {
     __shared__ float red[4];
