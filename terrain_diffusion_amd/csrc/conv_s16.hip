@@ -1,11 +1,14 @@
 // Deep-level latency flavour of the implicit-GEMM convolution (bf16 / fp16, gfx950), round 5: 64 pixels x 16 couts per workgroup on
-// v_mfma_f32_16x16x32, for the launches of a small batch whose maps are so small (8x8 and 16x16 levels of one 64x64 latent tile: BASELINE
-// configs[1]) that even the 64 x 32 tile of conv_sb.hip leaves three quarters of the chip idle.  conv_sb fills the chip there by splitting K over
-// WORKGROUPS as well -- fp32 partial planes and a reduce launch behind 44 of the 79 convs of a single-tile forward (4.7 us each, plus 0.3 GB of
-// partial-plane traffic per forward).  Here the cout tile is 16 wide instead: twice the workgroups per weight byte (48 at 8x8, 144 at 16x16 for one
-// tile), every weight byte still read by exactly one wave of one workgroup, K split only over the four waves of the workgroup -- no partial plane in
-// HBM and NO reduce launch.  What bounds such a layer is the weight stream a CU can ingest (~40 B/clk: conv_sb.hip), and a 16-cout workgroup
-// ingests 16 x K x 2 bytes: 221 KB for the 768 -> 768 conv of the 8x8 level = ~5.5 k cycles.
+// v_mfma_f32_16x16x32, for the launches of a small batch whose maps are so small (16x16 level of one 64x64 latent tile: BASELINE configs[1]) that even
+// the 64 x 32 tile of conv_sb.hip leaves most of the chip idle.  conv_sb fills the chip there by splitting K over WORKGROUPS as well -- fp32 partial
+// planes and a reduce launch behind 44 of the 79 convs of a single-tile forward (4.7 us each, plus 0.3 GB of partial-plane traffic per forward).
+// Here the cout tile is 16 wide instead: twice the workgroups per weight byte, every weight byte still read by exactly one wave of one workgroup,
+// K split only over the four waves of the workgroup -- no partial plane in HBM and NO reduce launch.
+// MEASURED (profiles/r05_conv_s16_deep_levels.txt): it wins where its grid reaches about half the chip -- the 16x16 level of one tile, 144
+// workgroups: 576 -> 576 8.9 / 11.8 us hot / cold against 10.1 / 14.5 for conv_sb + 3 K-slices + reduce -- and LOSES at the 8x8 level (48 workgroups:
+// 768 -> 768 12.1 us against 9.0): a workgroup streams 16 x K x 2 bytes (221 KB there) with 9 KiB in flight per wave = 36 KB per CU, ~20 GB/s per CU at
+// ~2 us of loaded latency, and 48 CUs cannot match the 216 workgroups of the split-K plan.  The planner (engine.hip, option "s16") therefore takes this
+// flavour only where its grid has >= "s16_min_wgs" (128) workgroups; 24 of the 44 reduce launches stay.
 // Same maths / parameter block / fused prologues and epilogues as the other flavours (mp_layers.py:201-221, unet_block.py:116-156):
 //   * wave w = (half, gsel): it contracts channels [32 half, 32 half + 32) of every K-group whose index is gsel modulo 2 -- the K loop walks the
 //     3x3 K-groups in PAIRS, one halo patch per group of the pair, double-buffered (four patch buffers, ONE barrier per 18 taps);

@@ -523,7 +523,8 @@ static hipError_t launch_sb_cfg(const ConvParams& p, hipStream_t st) {
 
 // Tile configurations: mt = 32-pixel MFMA blocks per workgroup (4: 8x16 pixels, 16-wide maps and nt = 1 only; 2: 4x16 or 8x8 pixels, 1: 2x16 or 4x8),
 // nt = 32-cout blocks (1 or 2).  Round 5, the 128 px x 32 cout tile: the K loop is bound by what one CU can ingest, and per K-group this tile ingests
-// 36.9 KB of weights + 23 KB of patch = 60 KB against the 87.5 KB of the 64 x 64 tile with the SAME number of workgroups and MFMAs per wave.
+// 36.9 KB of weights + 23 KB of patch = 60 KB against the 87.5 KB of the 64 x 64 tile with the SAME number of workgroups and MFMAs per wave.  Measured
+// level (slower in a hot loop, equal cold, -1 ... +2.5 % of a forward depending on the batch: profiles/r05_conv_sb_128px_tile.txt): opt-in, engine option sb_m4.
 // The caller sets tiles_x / tiles_y for that tile, img_groups = N, n_ntiles = CoutPad / (32 nt), ksplit (+ kb[], partial when > 1).
 template <typename T>
 static hipError_t launch_conv_sb_t(const ConvParams& p, bool narrow, int mt, int nt, hipStream_t st) {
