@@ -54,6 +54,7 @@ class ShardPlan:
         self.H, self.W, self.size, self.world = H, W, tile_size, world
         self.extended = bool(extended)
         stride = stride or tile_size // 2
+        self.stride = stride
         self.h_starts, self.w_starts = _tile_starts(H, tile_size, stride), _tile_starts(W, tile_size, stride)
         nr, nc = len(self.h_starts), len(self.w_starts)
         self.pr, self.pc = mesh_shape(world, nr, nc)
@@ -93,9 +94,15 @@ class ShardPlan:
         return {k: len(v) * channels * self.size * self.size * 4 for k, v in self.sends.items()}
 
 
-def exchange_windows(plan: ShardPlan, rank, my_tiles, group=None):
+def exchange_windows(plan: ShardPlan, rank, my_tiles, group=None, seam_comm=None):
     """my_tiles: [len(plan.windows[rank]), C, S, S] outputs of this rank's windows (device of the backend).  Returns
-    {(ic, jc): tile} for every window this rank's region needs (local ones included)."""
+    {(ic, jc): tile} for every window this rank's region needs (local ones included).
+    seam_comm (seam.SeamComm): send the windows through the C-ABI's td_seam_exchange_windows (include/td_seam.h: one grouped ncclSend/ncclRecv on
+    torch's current stream = the engine's stream inside the sharded samplers) instead of torch.distributed; same windows, same bits."""
+    if seam_comm is not None:
+        if seam_comm.rank != rank or seam_comm.world != plan.world:
+            raise ValueError(f"seam_comm is rank {seam_comm.rank} of {seam_comm.world}, the exchange is for rank {rank} of {plan.world}")
+        return seam_comm.exchange_windows(plan, my_tiles.contiguous())
     local_index = {w: i for i, w in enumerate(plan.windows[rank])}
     have = {w: my_tiles[local_index[w]] for w in plan.needed[rank] if plan.owner[w] == rank}
     ops, recv_bufs = [], {}
@@ -187,17 +194,18 @@ def engine_fns(model, scheduler, plan, cond_inputs, *, cond_means, cond_stds, no
 
 def sample_base_diffusion_sharded(model, scheduler, shape, cond_inputs, *, cond_means, cond_stds, noise_level=0.0, histogram_raw, steps=15,
                                   tile_size=64, noise_seed=42 + 5819, noise_origin=(0, 0), max_batch=64, group=None, gather_to=None,
-                                  sample_fn=None, blend_fn=None, normalize_fn=None, stats=None, _on_engine_stream=False):
+                                  sample_fn=None, blend_fn=None, normalize_fn=None, stats=None, seam_comm=None, _on_engine_stream=False):
     """Sharded sample_base_diffusion (terrain_diffusion/training/evaluation/sample_diffusion_base.py:115-168).
     Returns (region_tensor (C,h,w), (y0,y1,x0,x1)) for this rank, or the assembled (1,C,H,W) on rank `gather_to`.
-    sample_fn / blend_fn / normalize_fn default to the HIP engine; tests inject CPU stand-ins to exercise the plumbing under gloo."""
+    sample_fn / blend_fn / normalize_fn default to the HIP engine; tests inject CPU stand-ins to exercise the plumbing under gloo.
+    seam_comm: a seam.SeamComm -> the seam exchange goes through the C-ABI (td_seam_exchange_windows) instead of torch.distributed."""
     if sample_fn is None and model is not None and not _on_engine_stream:
         # engine path: everything below runs on the engine's side stream (see _engine_stream); the flag travels as an argument, not as global
         # state, so concurrent callers (threads, devices) cannot see each other's
         with _engine_stream(model):
             return sample_base_diffusion_sharded(model, scheduler, shape, cond_inputs, cond_means=cond_means, cond_stds=cond_stds, noise_level=noise_level,
                                                  histogram_raw=histogram_raw, steps=steps, tile_size=tile_size, noise_seed=noise_seed, noise_origin=noise_origin,
-                                                 max_batch=max_batch, group=group, gather_to=gather_to, stats=stats, _on_engine_stream=True)
+                                                 max_batch=max_batch, group=group, gather_to=gather_to, stats=stats, seam_comm=seam_comm, _on_engine_stream=True)
     B, C_, H, W = shape
     assert B == 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -214,7 +222,7 @@ def sample_base_diffusion_sharded(model, scheduler, shape, cond_inputs, *, cond_
         if my_tiles.is_cuda:
             torch.cuda.synchronize(my_tiles.device)
         t0 = time.perf_counter()
-    have = exchange_windows(plan, rank, my_tiles, group) if world > 1 else {w: my_tiles[i] for i, w in enumerate(plan.windows[rank])}
+    have = exchange_windows(plan, rank, my_tiles, group, seam_comm) if world > 1 else {w: my_tiles[i] for i, w in enumerate(plan.windows[rank])}
     if stats is not None:
         if my_tiles.is_cuda:
             torch.cuda.synchronize(my_tiles.device)
@@ -279,7 +287,7 @@ def consistency_engine_fns(model, plan, cond_inputs, *, cond_means, cond_stds, n
 
 def sample_base_consistency_sharded(model, scheduler, shape, cond_inputs, *, cond_means, cond_stds, noise_level=0.0, histogram_raw, intermediate_t=0.0,
                                     tile_size=64, noise_seed=42 + 5819, noise_origin=(0, 0), max_batch=64, group=None, gather_to=None,
-                                    step_fn=None, blend_fn=None, normalize_fn=None, stats=None, _on_engine_stream=False):
+                                    step_fn=None, blend_fn=None, normalize_fn=None, stats=None, seam_comm=None, _on_engine_stream=False):
     """Sharded sample_base_consistency (sample_diffusion_base.py:171-268; the latent stage's blended trig-flow phases, world_pipeline.py:1133-1203).
     T phases = T seam exchanges: in every phase a rank runs one consistency step on ITS windows, then receives the outputs of the
     neighbours' windows it needs and blends
@@ -292,7 +300,7 @@ def sample_base_consistency_sharded(model, scheduler, shape, cond_inputs, *, con
             return sample_base_consistency_sharded(model, scheduler, shape, cond_inputs, cond_means=cond_means, cond_stds=cond_stds, noise_level=noise_level,
                                                    histogram_raw=histogram_raw, intermediate_t=intermediate_t, tile_size=tile_size, noise_seed=noise_seed,
                                                    noise_origin=noise_origin, max_batch=max_batch, group=group, gather_to=gather_to, stats=stats,
-                                                   _on_engine_stream=True)
+                                                   seam_comm=seam_comm, _on_engine_stream=True)
     B, C_, H, W = shape
     assert B == 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -311,7 +319,7 @@ def sample_base_consistency_sharded(model, scheduler, shape, cond_inputs, *, con
         last = k == len(t_scalars) - 1
         plan = own if last else ext
         out = step_fn(mine, k, t, prev_tiles)
-        have = exchange_windows(plan, rank, out, group) if world > 1 else {w: out[i] for i, w in enumerate(mine)}
+        have = exchange_windows(plan, rank, out, group, seam_comm) if world > 1 else {w: out[i] for i, w in enumerate(mine)}
         if stats is not None:
             stats["exchanges"] = stats.get("exchanges", 0) + (1 if world > 1 else 0)
             stats["seam_bytes_total"] = stats.get("seam_bytes_total", 0) + sum(plan.seam_bytes(C_).values())
