@@ -5,11 +5,12 @@ slot layout), not link bandwidth.  Stages print one line each; the test asserts 
 
   A  one message to self, on a side stream, bit-exact
   B  23 messages of ragged sizes to self in ONE group, absolute addresses (base NULL)
-  C  a 2-rank and a 4-rank plan with every simulated rank's sends and receives posted to self: each rank ends up with exactly the windows its
+  C  2-, 4- and 8-rank plans (owned and extended regions) with every simulated rank's sends and receives posted to self: each rank ends up with exactly the windows its
      region needs, bit-exact (the cuts of sender and receiver pair up on hardware as tests/test_seam_cpu.py says they do on paper)
   D  engine sampling -> td_seam_exchange on the ENGINE's stream -> blend, 2 and 4 simulated ranks, batch-invariant mode: the assembled canvas is
      bit-identical to the unsharded sampler (the same claim test_sharded_sampling_simulated_ranks makes for the in-memory exchange)
   E  SeamComm.exchange_windows at world 1 (nothing crosses a seam): returns the rank's own windows, no RCCL call hangs on an empty exchange
+  F  (measurement) the cost of POSTING one exchange of BASELINE configs[3] on 8 ranks, busiest rank, looped back on this GPU
 """
 import os
 import sys
@@ -147,6 +148,36 @@ def main():
     have = comm.exchange_windows(plan1, mine)
     assert sorted(have) == sorted(plan1.needed[0]) and all(torch.equal(have[w].cpu(), fake(w, S)) for w in have)
     print("SEAM_E_OK", flush=True)
+
+    # F (a measurement, not a check): what one exchange of BASELINE configs[3] costs to POST -- the 32x32 window grid on 8 ranks, the busiest rank's
+    # sends looped back to itself (same message count and sizes as on 8 GPUs; the copies are local, so the stream time is not the xGMI time)
+    import time
+    cplan = seam.CShardPlan(1056, 1056, 64, 8)
+    wb = 5 * 64 * 64 * 4
+    r = max(range(8), key=lambda k: len(cplan.messages(k, wb)[0]))
+    s_msgs, r_msgs = cplan.messages(r, wb)
+    mine = torch.randn(len(cplan.windows_of(r, seam.OWN)[0]), 5, 64, 64, device=dev)
+    back = torch.empty(sum(n for _, _, n in s_msgs) // 4, device=dev)
+    sends = [(0, off, n) for _, off, n in s_msgs]
+    recvs, pos = [], 0
+    for _, _, n in s_msgs:
+        recvs.append((0, pos, n))
+        pos += n
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for it in range(3):
+        comm.exchange(mine, sends, back, recvs)
+    torch.cuda.synchronize()
+    host = []
+    e0.record()
+    for it in range(20):
+        t0 = time.perf_counter()
+        comm.exchange(mine, sends, back, recvs)
+        host.append(time.perf_counter() - t0)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"SEAM_F configs[3] on 8 ranks, rank {r} of mesh {cplan.pr}x{cplan.pc}: {len(s_msgs)} sends + {len(r_msgs)} receives per exchange "
+          f"({sum(n for _, _, n in s_msgs) / 1e6:.2f} MB out, {sum(n for _, _, n in r_msgs) / 1e6:.2f} MB in); looped back on one GPU ({len(sends)} + {len(recvs)} messages in one group): "
+          f"host enqueue {1e6 * sorted(host)[len(host) // 2]:.0f} us median, stream time {1e3 * e0.elapsed_time(e1) / 20:.0f} us per exchange", flush=True)
     comm.close()
 
 
