@@ -118,6 +118,36 @@ def test_committed_bench_line_honours_the_contract():
     assert abs(d["value"] - d["config"]["decoded_mp_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
 
 
+def test_round5_bench_line_belongs_to_the_sources_in_the_tree():
+    """profiles/r05_bench_grid8.json (the stamped round-5 line): its counter file carries the build id of the library that ran, and that id is the
+    hash of the kernel sources in THIS tree (csrc/* + include/td_engine.h) -- a later edit of the kernels without a re-collection fails here; the
+    roofline fraction follows from flop_per_launch and the live launch time, the rocprofv3 trace of the same command agrees with it, and the two
+    traffic ratios (with / without the optional second output counted as algorithmic) are what the counters and the labels give."""
+    import csv
+    import json
+    import __graft_entry__ as ge
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.loads(open(os.path.join(root, "profiles", "r05_bench_grid8.json")).read().strip().splitlines()[-1])
+    pj = json.load(open(os.path.join(root, "profiles", "r05_hbm_traffic_and_mfma_util.json")))
+    r = d["roofline"]
+    assert r["library_build_id"] == pj["library_build_id"] == pj["csrc_sha16"] == ge.csrc_sha16()
+    assert "configs[2]" in d["config"]["workload"] and d["dtype"] == "bf16" and d["vs_baseline"] is None and d["n_gpus"] == 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["peak"] == 2500.0 and r["bound"] == "mfma"
+    assert abs(r["achieved"] - r["flop_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12) / r["achieved"] < 0.01
+    # the kernel trace of the same command: call-weighted average launch time of the conv_glds instantiations within 3 % of the live one
+    rows = [x for x in csv.DictReader(open(os.path.join(root, "profiles", "r05_bench_grid8_kernel_trace_summary.csv"))) if "conv_glds_kernel" in x["kernel"]]
+    calls, total = sum(int(x["calls"]) for x in rows), sum(float(x["total_us"]) for x in rows)
+    assert calls % r["launches_per_step"] == 0 and abs(total / calls - r["avg_launch_us"]) / r["avg_launch_us"] < 0.03
+    # traffic: measured bytes per launch over the algorithmic bytes, with and without the pre-activated second output
+    assert r["traffic_algorithmic_strict"] < r["traffic_algorithmic"] < r["traffic"]
+    assert abs(r["traffic_over_algorithmic"] - r["traffic"] / r["traffic_algorithmic"]) < 2e-3
+    assert abs(r["traffic_over_algorithmic_strict"] - r["traffic"] / r["traffic_algorithmic_strict"]) < 2e-3
+    assert abs(d["value"] - d["config"]["decoded_mp_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "MP/s" and c["cores"] >= 1 and "sample" in c
+    assert d["roofline_single_tile"]["bound"] == "hbm" and 15.0 < d["latency_single_tile_ms"] < 25.0
+
+
 def test_unsupported_constructor_arguments_are_refused_before_the_engine_starts():
     """reference options the accelerated path does not carry are refused loudly (never silently remapped): block_kwargs / encode_only,
     fourier_scale != 'pos', 'embedding' conditional inputs, and noise_emb_dims=0 (edm_unet.py:49: 0 disables the noise input)."""
