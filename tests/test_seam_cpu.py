@@ -99,10 +99,11 @@ def test_message_cuts_of_sender_and_receiver_agree(case):
 
 
 def test_neighbouring_windows_travel_as_one_message():
-    """configs[3]'s 33x33 grid on 8 ranks (4x2 mesh): a block's last window row is contiguous in its own-order array -> ONE message to the
-    neighbour below, not one per window; the last column is strided -> one message per window."""
+    """configs[3]'s 32x32 window grid on 8 ranks (2x4 mesh, 16x8 windows per block): a block's last window row is contiguous in its own-order
+    array -> ONE message to the neighbour below, not one per window; the last column is strided -> one message per window."""
     from terrain_diffusion_amd import seam
-    c = seam.CShardPlan(1056 + 32, 1056 + 32, 64, 8)
+    c = seam.CShardPlan(1056, 1056, 64, 8)
+    assert (c.pr, c.pc, c.n_rows, c.n_cols) == (2, 4, 32, 32)
     wb = 5 * 64 * 64 * 4
     sends, _ = c.messages(0, wb)
     wins, dst = c.windows_of(0, seam.SENDS)
@@ -139,3 +140,42 @@ def test_exchange_windows_rejects_a_foreign_communicator():
     fake = seam.SeamComm(None, world=1, rank=0, device=0)
     with pytest.raises(ValueError, match="seam_comm is rank 0 of 1"):
         exchange_windows(plan, 0, torch.zeros(len(plan.windows[0]), 5, 64, 64), seam_comm=fake)
+
+
+def test_headers_are_plain_c_and_a_c_host_reads_the_same_plan(tmp_path):
+    """include/td_engine.h and include/td_seam.h compile as C99 (no C++ in the boundary), and a C program linked against libtd_seam.so
+    (tests/seam_host.c: the non-Python host the header is for) prints the plan parallel.ShardPlan computes."""
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    from terrain_diffusion_amd import seam
+    from terrain_diffusion_amd.parallel import ShardPlan
+    inc = os.path.join(ROOT, "include")
+    for h in ("td_engine.h", "td_seam.h"):
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c", os.path.join(inc, h)])
+    exe = str(tmp_path / "seam_host")
+    libdir = os.path.dirname(seam.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, os.path.join(ROOT, "tests", "seam_host.c"), "-o", exe,
+                           "-L", libdir, "-ltd_seam", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"])
+    wb = 5 * 64 * 64 * 4
+    for (H, W, tile, stride, world, extended) in ((1056, 1056, 64, 0, 8, 0), (1056, 1056, 64, 0, 8, 1), (160, 224, 64, 0, 2, 0), (100, 37, 16, 8, 3, 1)):
+        py = ShardPlan(H, W, tile, world, stride=stride or None, extended=bool(extended))
+        c = seam.CShardPlan(H, W, tile, world, stride=stride or None, extended=bool(extended))
+        for rank in range(world):
+            out = subprocess.run([exe, *map(str, (H, W, tile, stride, world, extended, rank, wb))], capture_output=True, text=True, timeout=60)
+            assert out.returncode == 0, out.stderr
+            lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
+            assert lines["mesh"] == f"{py.pr} {py.pc} {len(py.h_starts)} {len(py.w_starts)}"
+            assert lines["region"] == " ".join(str(v) for v in py.regions[rank])
+
+            def fmt(wins, peers):
+                return f"{len(wins)}:" + "".join(f" {i},{j}@{p_}" for (i, j), p_ in zip(wins, peers))
+            assert lines["own"] == fmt(py.windows[rank], [rank] * len(py.windows[rank]))
+            assert lines["needed"] == fmt(py.needed[rank], [py.owner[w] for w in py.needed[rank]])
+            snd = [(w, d) for (s_, d), wins in sorted(py.sends.items()) if s_ == rank for w in wins]
+            rcv = [(w, s_) for (s_, d), wins in sorted(py.sends.items()) if d == rank for w in wins]
+            assert lines["sends"] == fmt([w for w, _ in snd], [d for _, d in snd])
+            assert lines["recvs"] == fmt([w for w, _ in rcv], [s_ for _, s_ in rcv])
+            ms, mr = c.messages(rank, wb)
+            assert lines["send_msgs"] == f"{len(ms)}:" + "".join(f" {p_}:{o}+{n}" for p_, o, n in ms)
+            assert lines["recv_msgs"] == f"{len(mr)}:" + "".join(f" {p_}:{o}+{n}" for p_, o, n in mr)
