@@ -78,7 +78,7 @@ int td_seam_plan_messages(const td_seam_plan* plan, int rank, int64_t window_byt
 /* Rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by the host's own means (the Python host: torch.distributed
  * broadcast_object_list; a C host: its launcher / a file / MPI). */
 int td_seam_unique_id(void* id128);
-/* ncclCommInitRank on `device` (collective over the `world` ranks). */
+/* ncclCommInitRank on `device` (collective over the `world` ranks).  Leaves `device` the calling thread's current device, as hipSetDevice does. */
 int td_seam_comm_create(int device, int world, int rank, const void* id128, td_seam_comm** comm);
 /* Wraps a communicator the host already has (an ncclComm_t); it is not destroyed with the handle. */
 int td_seam_comm_adopt(void* nccl_comm, td_seam_comm** comm);
@@ -88,7 +88,8 @@ int td_seam_comm_info(const td_seam_comm* comm, int32_t info[3]);
 
 /* ---- the exchange ---------------------------------------------------------------------------------------------------------------------- */
 /* All messages as ONE ncclGroup of ncclSend / ncclRecv on `hip_stream` (device memory; a base may be NULL when its offsets are absolute
- * addresses).  Enqueue-only: returns once the group is launched.  A message to the rank itself is legal (RCCL copies locally). */
+ * addresses).  Enqueue-only: returns once the group is launched.  A message to the rank itself is legal (RCCL copies locally).  The group is
+ * posted with the communicator's device current; the caller's current device is restored before returning. */
 int td_seam_exchange(td_seam_comm* comm, const void* send_base, const td_seam_msg* sends, int n_sends, void* recv_base, const td_seam_msg* recvs,
                      int n_recvs, void* hip_stream);
 /* The seam exchange of one phase (parallel.py::exchange_windows): my_tiles = the rank's window outputs in OWN order, recv_tiles = room for

@@ -310,6 +310,14 @@ int td_seam_exchange(td_seam_comm* comm, const void* send_base, const td_seam_ms
     }
     if (n_sends + n_recvs == 0) return TD_SEAM_OK;
     hipStream_t st = (hipStream_t)hip_stream;
+    // RCCL posts on the communicator's device: make it current for the group and put the caller's back afterwards
+    int prev = comm->device;
+    if (hipGetDevice(&prev) != hipSuccess) prev = comm->device;
+    if (prev != comm->device && hipSetDevice(comm->device) != hipSuccess) return fail(TD_SEAM_ERR_HIP, "hipSetDevice to the communicator's device failed");
+    struct Restore {
+        int prev, cur;
+        ~Restore() { if (prev != cur) (void)hipSetDevice(prev); }
+    } restore{prev, comm->device};
     ncclResult_t r = ncclGroupStart();
     if (r != ncclSuccess) return rccl_fail("ncclGroupStart", r);
     ncclResult_t bad = ncclSuccess;
