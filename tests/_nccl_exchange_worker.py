@@ -1,8 +1,9 @@
 """torchrun worker of tests/test_gpu_bench_config.py::test_nccl_seam_exchange_two_gpus: the RCCL seam exchange on real device tensors.
 Every rank fabricates deterministic 'window outputs' (a function of the window index only), exchanges them with exchange_windows over the
 nccl backend and checks that every window its region needs arrived bit-exactly; then the sharded sampler runs on a tiny model in
-batch-invariant mode and the gathered canvas must equal the single-GPU canvas bit for bit.  Both are then repeated with the seam exchange going
-through the C-ABI (libtd_seam.so: its own RCCL communicator, one grouped ncclSend/ncclRecv on the engine's stream)."""
+batch-invariant mode and the gathered canvas must equal the single-GPU canvas bit for bit.  With the argument `capi`
+(test_gpu_seam.py::test_capi_seam_exchange_two_gpus) both are repeated with the seam exchange going through the C-ABI (libtd_seam.so: its own RCCL
+communicator, one grouped ncclSend/ncclRecv on the engine's stream); the two transports are separate tests so that a failure names its transport."""
 import os
 import sys
 
@@ -45,19 +46,21 @@ def main():
     if rank == 0:
         single = td.sample_base_diffusion(m, sch, (1, 5, H, W), cond, **kw)
         assert torch.equal(full, single), float((full - single).abs().max())
-    # the same exchange and the same sharded sampler through the C-ABI transport (include/td_seam.h: td_seam_exchange_windows on torch's current stream)
-    from terrain_diffusion_amd.seam import SeamComm
-    sc = SeamComm.create(dev)
-    have_c = exchange_windows(plan, rank, mine, seam_comm=sc)
-    torch.cuda.synchronize()
-    assert sorted(have_c) == sorted(plan.needed[rank])
-    for w, t in have_c.items():
-        assert torch.equal(t.cpu(), fake(w)), ("c-abi", rank, w)
-    full_c = sample_base_diffusion_sharded(m, sch, (1, 5, H, W), cond, gather_to=0, seam_comm=sc, **kw)
-    if rank == 0:
-        assert torch.equal(full_c, single)
         print("NCCL_EXCHANGE_OK", flush=True)
-    sc.close()
+    if "capi" in sys.argv[1:]:
+        # the same exchange and the same sharded sampler through the C-ABI transport (include/td_seam.h: td_seam_exchange_windows on torch's current stream)
+        from terrain_diffusion_amd.seam import SeamComm
+        sc = SeamComm.create(dev)
+        have_c = exchange_windows(plan, rank, mine, seam_comm=sc)
+        torch.cuda.synchronize()
+        assert sorted(have_c) == sorted(plan.needed[rank])
+        for w, t in have_c.items():
+            assert torch.equal(t.cpu(), fake(w)), ("c-abi", rank, w)
+        full_c = sample_base_diffusion_sharded(m, sch, (1, 5, H, W), cond, gather_to=0, seam_comm=sc, **kw)
+        if rank == 0:
+            assert torch.equal(full_c, single)
+            print("CAPI_EXCHANGE_OK", flush=True)
+        sc.close()
     dist.barrier()
     dist.destroy_process_group()
 
