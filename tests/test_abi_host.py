@@ -29,6 +29,28 @@ def test_library_exports_every_declared_symbol():
     assert set(EXPORTS) == set(declared), set(EXPORTS) ^ set(declared)
 
 
+def test_a_c_host_links_the_engine_library_and_gets_no_cpu_fallback(tmp_path):
+    """tests/engine_host.c (C99) against libtd_engine.so: version / build id / _tile_seed answer on the host; without a GPU td_engine_create
+    returns a negative code and a message instead of an engine."""
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    import terrain_diffusion_amd as td
+    from terrain_diffusion_amd._lib import LIB_PATH
+    libdir = os.path.dirname(LIB_PATH)
+    exe = str(tmp_path / "engine_host")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "engine_host.c"), "-o", exe,
+                           "-L", libdir, "-ltd_engine", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
+    assert lines["build"] == ge.csrc_sha16() and int(lines["version"]) >= 1
+    assert int(lines["seed"]) == td._tile_seed(5861, -3, 7)
+    if not torch.cuda.is_available():
+        code, msg = lines["engine_create"].split(":", 1)
+        assert int(code) < 0 and len(msg.strip()) > 8, lines
+
+
 def test_no_cpu_fallback_is_loud():
     """without a GPU the engine refuses to start instead of silently computing on the CPU."""
     if torch.cuda.is_available():
