@@ -11,7 +11,6 @@ torchvision itself is not installed here, so those two operators are PARITY-UNPI
 F.interpolate / conv2d in tests (oracle/compose.py), which is what torchvision calls.
 """
 import ctypes as C
-import math
 
 import functools
 

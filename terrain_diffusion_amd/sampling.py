@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from ._lib import lib, check
-from .engine import ptr, f32
+from .engine import ptr
 from . import noise as _noise
 
 

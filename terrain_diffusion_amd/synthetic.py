@@ -6,7 +6,6 @@ The same recipe is restated on the CPU in oracle/unet.py:synth_state_dict for th
 """
 import math
 
-import numpy as np
 import torch
 
 from . import noise as _noise
