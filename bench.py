@@ -135,7 +135,8 @@ def main():
     seam = {}
     strong = workload == "grid32"
     if strong:
-        eng.set_option("batch_invariant", 1)   # the sharded canvas is then bit-identical to the single-GPU canvas (tests/test_parallel_cpu.py)
+        if "batch_invariant=" not in args.engine_opts:
+            eng.set_option("batch_invariant", 1)   # the sharded canvas is then bit-identical to the single-GPU canvas (tests/test_parallel_cpu.py)
         if "dual_stream=" not in args.engine_opts:
             # two concurrent half-batch lanes per rank (engine option dual_stream): +5.7 % on this workload in a same-box A/B -- batch-invariant mode
             # has no split-K, so the small levels leave more CUs idle per launch for the other lane to fill; bits unchanged (test_sharded_sampling_simulated_ranks)

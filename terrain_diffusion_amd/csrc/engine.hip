@@ -510,17 +510,25 @@ static int pack_conv(td_unet* u, ConvWeights& cw) {
 // for the 30m base model when every conv of a single-tile forward runs on that flavour, nothing for models that never leave the throughput flavour.
 static int ensure_packed_sb(td_unet* u, ConvWeights& cw) {
     if (cw.packed_sb || cw.sb_n3 < 0) return TD_OK;
-    cw.packed_sb.reset(new DevBuf());
-    HIP_TRY(cw.packed_sb->alloc(cw.packed_bytes + 16384, true));   // (alloc synchronises behind its zero fill)
-    HIP_TRY(launch_sb_repack(cw.packed->p, cw.packed_sb->p, cw.cout_pad, cw.sb_n3, cw.sb_g1, u->eng->stream));
+    // Built into a local buffer and published only when allocation, launch AND completion succeeded (round-5 advisor): a failed repack must not leave a
+    // zero-filled copy that the next plan would silently use, and the copy is read by launches on EITHER sampler lane's stream (dual_stream: the second
+    // lane builds its plan after the stream swap, finds the copy present and launches on stream2 with no dependency on the stream that made it) --
+    // so this setup-time step waits for its own stream before the pointer becomes visible.  Once per op and model, never in the steady state.
+    Buf b(new DevBuf());
+    HIP_TRY(b->alloc(cw.packed_bytes + 16384, true));   // (alloc synchronises behind its zero fill)
+    HIP_TRY(launch_sb_repack(cw.packed->p, b->p, cw.cout_pad, cw.sb_n3, cw.sb_g1, u->eng->stream));
+    HIP_TRY(hipStreamSynchronize(u->eng->stream));
+    cw.packed_sb = std::move(b);
     return TD_OK;
 }
 
 static int ensure_packed_s16(td_unet* u, ConvWeights& cw) {
     if (cw.packed_s16 || cw.sb_n3 < 0) return TD_OK;
-    cw.packed_s16.reset(new DevBuf());
-    HIP_TRY(cw.packed_s16->alloc(cw.packed_bytes + 16384, true));
-    HIP_TRY(launch_s16_repack(cw.packed->p, cw.packed_s16->p, cw.cout_pad, cw.sb_n3, cw.sb_g1, u->eng->stream));
+    Buf b(new DevBuf());   // (published after completion only: see ensure_packed_sb)
+    HIP_TRY(b->alloc(cw.packed_bytes + 16384, true));
+    HIP_TRY(launch_s16_repack(cw.packed->p, b->p, cw.cout_pad, cw.sb_n3, cw.sb_g1, u->eng->stream));
+    HIP_TRY(hipStreamSynchronize(u->eng->stream));
+    cw.packed_s16 = std::move(b);
     return TD_OK;
 }
 

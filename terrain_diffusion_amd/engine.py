@@ -21,10 +21,11 @@ class Engine:
     def set_async(self, on):
         """option "async": calls on device tensors only enqueue (see on_stream)."""
         self.set_option("async", 1 if on else 0)
-        self._async = bool(on)
 
     def set_option(self, key, value):
         check(lib().td_engine_set_option(self._h, key.encode(), int(value)))
+        if key == "async":   # the shadow on_stream restores on exit follows the documented C-ABI knob, whoever sets it (round-5 advisor)
+            self._async = bool(int(value))
 
     def synchronize(self):
         check(lib().td_engine_synchronize(self._h))

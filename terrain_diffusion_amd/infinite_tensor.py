@@ -383,10 +383,12 @@ class DeviceWindowTensor(InfiniteTensor):
                 out[c] = t
         return out
 
-    def gather_many(self, bounds):
+    def gather_many(self, bounds, tiles=None):
         """bounds: [((0, C+1), (y0, y1), (x0, x1)), ...], all regions of one size -> device tensor (n, C+1, y1-y0, x1-x0): every region assembled
         from the raw window outputs by ONE launch of the engine's region-gather kernel (td_gather_regions), same per-pixel window order and
-        arithmetic as the region-by-region path.  Missing windows (and their upstream) are computed first, in as few batches as allowed."""
+        arithmetic as the region-by-region path.  Missing windows (and their upstream) are computed first, in as few batches as allowed.
+        `tiles`: windows the caller already holds ({ctx: tensor}, e.g. the pre-ensured windows of a large region): consulted before the tile store,
+        so a window evicted from a small store between two cells of one read is not evaluated a second time."""
         import numpy as np
         from ._lib import lib, check
         from .engine import ptr
@@ -394,7 +396,15 @@ class DeviceWindowTensor(InfiniteTensor):
         h, w = bounds[0][1][1] - bounds[0][1][0], bounds[0][2][1] - bounds[0][2][0]
         assert all(b[1][1] - b[1][0] == h and b[2][1] - b[2][0] == w for b in bounds), "gather_many: regions of one size only"
         per = [sorted(self._windows_for([0, b[1][0], b[2][0]], [self.channels + 1, b[1][1], b[2][1]])) for b in bounds]
-        tiles = self._ensure(sorted({c for p_ in per for c in p_}))
+        need = sorted({c for p_ in per for c in p_})
+        if tiles is not None:
+            held = {c: tiles[c] for c in need if c in tiles}
+            rest = [c for c in need if c not in held]
+            if rest:
+                held.update(self._ensure(rest))
+            tiles = {c: held[c] for c in need}
+        else:
+            tiles = self._ensure(need)
         order = {c: k for k, c in enumerate(tiles)}
         maxk = max(1, max(len(p_) for p_ in per))
         desc = np.full((n, maxk, 3), -1, dtype=np.int32)
@@ -421,7 +431,10 @@ class DeviceWindowTensor(InfiniteTensor):
         same windows are summed in the same ascending (row, col) order as in the one-region path -- bit-identical, but O(cell windows) per pixel."""
         C1 = self.channels + 1
         step = 3 * self.stride_hw
-        self._ensure(sorted(self._windows_for([0, lo[1], lo[2]], [C1, hi[1], hi[2]])))   # missing windows of the WHOLE region in as few batches as allowed
+        # missing windows of the WHOLE region in as few batches as allowed -- and HELD for the duration of the read (round-5 advisor: with only the LRU
+        # store keeping them alive, a region that touches more windows than the store holds evicted its early windows before their cell's gather ran,
+        # and recomputing those evicted later ones in turn: several U-Net evaluations per window)
+        held = self._ensure(sorted(self._windows_for([0, lo[1], lo[2]], [C1, hi[1], hi[2]])))
 
         def cuts(l, h, o):
             first = ((l - o) // step + 1) * step + o
@@ -441,7 +454,7 @@ class DeviceWindowTensor(InfiniteTensor):
         for ky, ny, h in classes(ys):
             for kx, nx, w in classes(xs):
                 bounds = [((0, C1), (ys[ky + a], ys[ky + a] + h), (xs[kx + b], xs[kx + b] + w)) for a in range(ny) for b in range(nx)]
-                res = self.gather_many(bounds)   # (ny * nx, C1, h, w)
+                res = self.gather_many(bounds, tiles=held)   # (ny * nx, C1, h, w)
                 y0, x0 = ys[ky] - lo[1], xs[kx] - lo[2]
                 out[:, y0:y0 + ny * h, x0:x0 + nx * w] = res.view(ny, nx, C1, h, w).permute(2, 0, 3, 1, 4).reshape(C1, ny * h, nx * w)
         return out

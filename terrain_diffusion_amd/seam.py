@@ -150,6 +150,20 @@ class SeamComm:
             lib().td_seam_comm_destroy(self._h)
             self._h = None
 
+    # a communicator is a device resource: usable as `with SeamComm.create(...) as comm:`; a forgotten one is destroyed with the object
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown: the library may already be gone
+            pass
+
     def info(self):
         v = (C.c_int32 * 3)()
         check(lib().td_seam_comm_info(self._h, v))

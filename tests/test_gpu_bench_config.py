@@ -266,6 +266,46 @@ def test_config3_grid32_full_size_one_gpu(td, base):
         eng.set_option("batch_invariant", 0)
 
 
+@pytest.mark.parametrize("dual", [0, 1])
+def test_config3_default_plan_bit_identical_across_rank_counts(td, base, dual):
+    """BASELINE configs[3] WITHOUT batch_invariant.  At world 1 / 2 / 4 / 8 a rank owns 1024 / 512 / 256 / 128 windows and the
+    sampler cuts them into batches of max_batch = 64: every launch on every rank count has the same batch size, hence the same plan (tile shapes,
+    split-K, conv flavour) and the same K order -- a window's result must not depend on which 63 other windows ride in its batch or on its position in
+    it.  Full size, 20 steps, bf16, DEFAULT plan (and with the two sampler lanes bench.py's grid32 turns on): the one-rank canvas against the canvases
+    assembled from 2 and 4 simulated ranks, bit for bit.  Loop sharded: sample_diffusion_base.py:147-168."""
+    from oracle import tiling
+    from terrain_diffusion_amd.engine import get_engine
+    from terrain_diffusion_amd.parallel import ShardPlan, engine_fns, blend_region
+    m, om = base
+    eng = get_engine("cuda")
+    eng.set_option("batch_invariant", 0)
+    eng.set_option("dual_stream", dual)
+    try:
+        sch = td.EDMDPMSolverMultistepScheduler(sigma_min=0.002, sigma_max=80.0, sigma_data=0.5)
+        H = W = 1056
+        cond = tiling.synthetic_cond_grid(32, 32)
+        seed = 42 + 5819
+        kw = dict(cond_means=torch.zeros(7), cond_stds=torch.ones(7), noise_level=torch.tensor(0.0), histogram_raw=torch.zeros(1, 5))
+        y = td.sample_base_diffusion(m, sch, (1, 5, H, W), cond, steps=20, tile_size=64, noise_seed=seed, max_batch=64, **kw)
+        assert tuple(y.shape) == (1, 5, H, W) and torch.isfinite(y).all()
+        for world in (2, 4):
+            plan = ShardPlan(H, W, 64, world)
+            assert all(len(ws) % 64 == 0 for ws in plan.windows), [len(ws) for ws in plan.windows]
+            fns = engine_fns(m, sch, plan, cond, steps=20, channels=5, noise_seed=seed, noise_origin=(0, 0), max_batch=64, **kw)
+            tiles = [fns[0](plan.windows[r]) for r in range(world)]
+            full = torch.empty((5, H, W), device="cuda")
+            for r in range(world):
+                have = {w_: tiles[plan.owner[w_]][plan.windows[plan.owner[w_]].index(w_)] for w_ in plan.needed[r]}
+                y0, y1, x0, x1 = plan.regions[r]
+                full[:, y0:y1, x0:x1] = blend_region(plan, r, have, fns[1], fns[2], 5, 1.0 / 0.5)
+            nbad = int((full[None] != y).sum())
+            print(f"configs[3] default plan (dual_stream={dual}): {world}-rank canvas vs one-rank canvas: {nbad} differing values")
+            assert nbad == 0, f"{world}-rank canvas differs from the one-rank canvas in {nbad} values (default plan, dual_stream={dual})"
+            del tiles, full
+    finally:
+        eng.set_option("dual_stream", 0)
+
+
 def test_fp16_tile_variants_bit_identical_and_close_to_bf16(td):
     """fp16 storage runs through the same conv flavours (v_mfma_f32_32x32x16_f16): the tile-shape identity holds there too, and the result sits
     closer to the fp32 oracle than bf16's (10 vs 7 mantissa bits)."""
