@@ -134,13 +134,15 @@ def main():
                         for j in range(max(1, args.tiles_per_step))])
     seam = {}
     strong = workload == "grid32"
-    if strong:
-        if "batch_invariant=" not in args.engine_opts:
-            eng.set_option("batch_invariant", 1)   # the sharded canvas is then bit-identical to the single-GPU canvas (tests/test_parallel_cpu.py)
-        if "dual_stream=" not in args.engine_opts:
-            # two concurrent half-batch lanes per rank (engine option dual_stream): +5.7 % on this workload in a same-box A/B -- batch-invariant mode
-            # has no split-K, so the small levels leave more CUs idle per launch for the other lane to fill; bits unchanged (test_sharded_sampling_simulated_ranks)
-            eng.set_option("dual_stream", 1)
+    if strong and "batch_invariant=" not in args.engine_opts:
+        # The sharded canvas must be bit-identical to the single-GPU canvas.  When every rank's window list is a whole number of max_batch = 64 batches
+        # (world 1 / 2 / 4 / 8: 1024 / 512 / 256 / 128 windows per rank) every launch on every rank count has the same batch size, hence the same plan and
+        # K order, and the DEFAULT plan already gives that (test_config3_default_plan_bit_identical_across_rank_counts: 1 rank vs 2 / 4 simulated ranks,
+        # bit for bit, with and without the two sampler lanes).  Ragged shards (other rank counts) pin the plan with batch_invariant, which costs 7 %.
+        from terrain_diffusion_amd.parallel import ShardPlan
+        ragged = any(len(ws) % 64 for ws in ShardPlan(H, W, 64, world).windows)
+        eng.set_option("batch_invariant", 1 if ragged else 0)
+        eng_opts["batch_invariant"] = 1 if ragged else 0
 
     def one_step(i, b=None, wl=None):
         # different world regions each step (noise origins move), same as sampling successive regions of the world
@@ -193,7 +195,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": names[workload], "tiles_per_step": tiles_per_step, "edm_steps": E, "decoded_mp_per_step": mp_per_step,
-                   "parallelism": (f"{world} ranks, 2-D block mesh {seam.get('mesh')}, point-to-point seam exchange (no all-reduce), two sampler lanes per rank" if strong else
+                   "parallelism": (f"{world} ranks, 2-D block mesh {seam.get('mesh')}, point-to-point seam exchange (no all-reduce), two sampler lanes per rank, "
+                                   f"{'batch-invariant plan (ragged shards)' if eng_opts.get('batch_invariant') else 'default plan (whole batches of 64 windows per rank)'}" if strong else
                                    f"{world} independent streams (one process per GPU, no data-path collective)")},
     }
     if strong:
@@ -231,7 +234,7 @@ def main():
                                               "achieved": round(sb_gf / sb_ms, 2) if sb_ms > 0 else None, "unit": "TFLOP/s"}
             if g_n > 0:   # dominant kernel family: the LDS-DMA implicit-GEMM conv (terrain_diffusion_amd/csrc/conv_glds.hip)
                 ach = g_flop / (g_ms * 1e-3) / 1e12
-                dual_on = "dual_stream=1" in args.engine_opts or (strong and "dual_stream=0" not in args.engine_opts)
+                dual_on = "dual_stream=0" not in args.engine_opts   # engine default since round 6 (profiles/r06_dual_stream_ab.txt)
                 lanes = 2 if (dual_on and min(tiles_per_step, 64) >= 32) else 1
                 share = g_ms / (conv_ms + other_ms)
                 iso = {"achieved": round(ach, 2), "frac": round(ach / peak, 4), "avg_launch_us": round(g_ms / g_n * 1e3, 3), "kernel_ms_per_step": round(g_ms, 3)}
@@ -305,10 +308,9 @@ def main():
             # N = 1 point of the STRONG-scaling workload the driver runs at N > 1 (grid32, BASELINE configs[3]): one full step, timed live in this
             # run with the same engine options the sharded run uses, so that the 1 -> N curve has a same-run, same-node anchor
             from terrain_diffusion_amd.parallel import sample_base_diffusion_sharded
-            prev_opts = {k_: eng_opts.get(k_, 0) for k_ in ("batch_invariant", "dual_stream")}   # what --engine-opts asked for, restored afterwards
-            eng.set_option("batch_invariant", 1); eng.set_option("dual_stream", 1)
+            # (the sharded run's options: the default plan -- 1024 windows = 16 whole batches of 64 on one rank -- and the engine's two sampler lanes)
             try:
-                one_step(30_000, 64, "tiles"); sync()          # builds the batch-invariant plans and graphs of the two 32-window lanes
+                one_step(30_000, 64, "tiles"); sync()          # plans and graphs of the two 32-window lanes
                 nt32 = len(_tile_starts(1056, 64, 32))
                 cond32 = synthetic_cond_grid(nt32, nt32, device=dev)
                 a0 = time.perf_counter()
@@ -316,12 +318,15 @@ def main():
                 sync()
                 adt = time.perf_counter() - a0
                 mp32 = (1056 * 8) ** 2 / 1e6
-                result["strong_scaling_anchor"] = {"workload": "grid32 (BASELINE configs[3]) on ONE rank: 32x32 windows, 1056x1056 latents, 20 steps, batch-invariant, two sampler lanes",
+                result["strong_scaling_anchor"] = {"workload": "grid32 (BASELINE configs[3]) on ONE rank: 32x32 windows, 1056x1056 latents, 20 steps, default plan (16 whole batches of 64 windows), two sampler lanes",
                                                    "value": round(mp32 / adt, 4), "unit": "MP/s", "ms_per_step": round(adt * 1e3, 2), "steps_timed": 1,
-                                                   "note": "divide an N > 1 driver line's value by N x this to get the strong-scaling efficiency of that workload"}
+                                                   "ms_per_64_window_batch": round(adt * 1e3 / 16, 2),
+                                                   "note": "divide an N > 1 driver line's value by N x this to get the strong-scaling efficiency of that workload. A grid32 step is 16 batches "
+                                                           "of 64 windows for 71.37 MP (0.0697 MP per window: every window overlaps its neighbours by half), a grid8 step one batch for 5.31 MP "
+                                                           "(0.0829 MP per window: a quarter of the 8x8 canvas is border that one window covers alone) -- at equal time per batch grid32 reads "
+                                                           "0.84x grid8's MP/s"}
             finally:
-                for k_, v_ in prev_opts.items():
-                    eng.set_option(k_, v_)
+                pass
 
         if world == 1 and not args.no_cpu_baseline:
             # CPU baseline = the oracle (CPU restatement pinned to the reference) on this host's cores, bounded sample

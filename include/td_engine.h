@@ -83,14 +83,16 @@ int td_engine_set_stream(td_engine* e, void* hip_stream);
  *   "graph"=0/1 (hipGraph capture of the sampler loops), "profile"=0/1, "async"=0/1 (see td_engine_set_stream),
  *   "batch_invariant"=0/1 (a window's result does not depend on the batch / GPU it rides in: no split-K, LDS-DMA conv flavour pinned),
  *   "solver_order"=1/2/3 and "lower_order_final"=0/1 (EDMDPMSolverMultistepScheduler.config), "fuse_solver"=0/1 (solver update in the
- *   output conv's epilogue), "dual_stream"=0/1 + "dual_stream_min_batch" (two concurrent half-batch lanes), "plan_cache_mb", "plan_cache_max".
+ *   output conv's epilogue), "dual_stream"=0/1 (default 1) + "dual_stream_min_batch" (default 32: batches at least that large run as two concurrent half-batch lanes), "plan_cache_mb", "plan_cache_max".
  * Plan builder (speed only; every one is part of the plan-cache key):
  *   "glds", "glds_min_wgs", "glds_bn64", "glds_round_aware", "glds_small_max_groups", "glds_dma1x1", "glds_tiny", "bn128_min_wgs",
  *   "splitk", "splitk_target_wgs", "splitk_weighted", "glds_splitk", "glds_splitk_from_groups", "glds_splitk_max", "glds_splitk_min_groups",
  *   "producer_act", "walk_alternate", "attn_mfma",
  *   "sb" (small-batch conv flavour), "sb_m4"=0/1 (its 128 px x 32 cout tile, off by default), "sb_target_wgs", "sb_order", "sb_max_glds_wgs", "sb_splitk", "sb_splitk_wgs", "sb_splitk_max",
  *   "s16"=0/1/2 (deep-level latency flavour, conv_s16.hip: never / where conv_sb would split K over workgroups and the 16-cout grid reaches
- *   "s16_min_wgs" workgroups / wherever conv_sb applies).
+ *   "s16_min_wgs" workgroups / wherever conv_sb applies),
+ *   "glds_wide"=0/1/2 (wide tile of the LDS-DMA flavour, conv_glds_wide.hip: never / pure-3x3 launches whose 256-pixel grid reaches "glds_wide_min_wgs"
+ *   (1024) workgroups / wherever it is legal).
  * Test hooks that force a tile shape wherever it is legal: "glds_variant"=-1/0/1, "glds_bn"=0/64/96/128, "sb_mt"=0/1/2/4, "sb_nt"=0/1/2. */
 int td_engine_set_option(td_engine* e, const char* key, int64_t value);
 

@@ -1,0 +1,502 @@
+// Wide tile of the LDS-DMA implicit-GEMM convolution (round 6): 256 pixels x BN couts per 4-wave workgroup, TWO workgroups per CU, 32-channel
+// K-groups with a DOUBLE-BUFFERED activation patch -- one seamless MFMA pipeline over the whole 3x3 part of a launch.
+//
+// conv_glds.hip's tiles are either 128 px x 96 / 128 couts on 4 waves (two workgroups per CU, but a wave owns 32 px x 96 couts or 64 x 64:
+// 4 fragment reads per 3 - 4 MFMAs, and every pixel tile re-streams the cout tile's whole weight tensor through the CU's L2 -> LDS path:
+// 12 KB per tap and 128 pixels) or 256 px on 8 waves (half the weight bytes per pixel, but 91 KB of LDS: ONE workgroup per CU, and what the
+// kernel lives on is two independent workgroups per CU whose prologues / restages / epilogues run under each other's MFMA stream -- DESIGN.md
+// section 4).  This flavour has both: a wave owns 64 px x BN couts (MT = 2, NT = BN / 32: 5 fragment reads per 6 MFMAs at BN = 96), the
+// workgroup 256 px (16 x 16), and the LDS footprint stays under half a CU because everything is kept in HALF K-steps:
+//   * a K-group is 32 channels x 9 taps; a ring slot holds the 32 channels x BN couts of one tap (BN x 64 B), three slots, one barrier per
+//     half K-step = per 2 x MT x NT MFMAs of a wave (the MFMA count the 128-pixel tile has per tap);
+//   * the halo patch holds 32 channels (18 x 18 pixels x 80-byte rows = 26 KB) and exists TWICE: while the taps of K-group g read one buffer, the
+//     patch of g + 1 is fetched (6 x 16 bytes per thread, registers) and written into the other.  There is no restage barrier and no pipeline
+//     bubble at a group boundary: the last half-step of a group requests the first fragments of the next one, across 64-channel chunks and
+//     across 3x3 segments alike.
+// Per MFMA the workgroup ingests half the weight bytes, reads 0.6x the LDS bytes and runs half as many prologues / epilogue drains.
+//
+// Same maths, parameter block, packed weight slab ([K-step][cout][128 B], conv_glds.hip's layout: no extra copy) and fused prologues / epilogues as
+// conv_glds.hip.  The K ORDER differs (64-channel chunk -> channel half -> tap -> two 16-deep k-steps, against chunk -> tap -> four k-steps): fp32
+// accumulation in another order, so results agree with the other tiles to fp32 rounding of the sums (<= 1 bf16 ulp on ~1 % of the outputs), not bit
+// for bit; a launch's flavour is a function of its shape and batch size only (planner), like conv_sb / conv_s16.
+//
+// The half K-step in LDS: row r (cout in tile) is 64 B = four 16-byte pieces; piece j of row r lies at r * 64 + ((j ^ ((r >> 2) & 3)) << 4).
+// A ds_read_b128 is serviced in the 16-lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (MI355X guide, LDS): each group holds four
+// runs of four consecutive rows whose (r >> 2) & 3 are pairwise different, so the 16 pieces of a fragment read fall on 16 different 16-byte
+// columns of the 256-byte bank window: conflict-free.  The LDS-DMA writes wave-linear (LDS[base + 16 * lane]); each lane's GLOBAL address
+// is free, so lane p copies the piece that belongs at position p: row p >> 2, piece (p & 3) ^ ((row >> 2) & 3), which the slab stores at
+// slot (4 h + piece) ^ TD_SWZ(row) of the row's 128 bytes -- i.e. the two channel halves of a K-step differ by `offset ^ 64`.
+// Patch rows are 80 bytes (64 + 16 of padding): 16 consecutive rows start at 16 different 16-byte columns of the bank window (5 is odd), and a
+// fragment address is "lane base + compile-time (buffer, tap, k-step) offset" -- no VALU in the tap loop, as in conv_glds.hip.
+#include "conv_common.h"
+
+namespace td {
+
+#ifndef TDW_XFORM_ON
+#define TDW_XFORM_ON 1
+#endif
+#ifdef TD_TRACE
+#define TDW_T(v) unsigned long long v = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define TDW_TACC(acc, a, b) acc += (b) - (a)
+#else
+#define TDW_T(v)
+#define TDW_TACC(acc, a, b)
+#endif
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams p) {
+    typedef typename Half<T>::x8 hx8;
+    constexpr int NTHR = 256, TH = 16, TW = 16, TPIX = 256;
+    constexpr int PW = 18, NPATCH = 18 * 18;
+    constexpr int WM = 64, MT = 2, NT = BN / 32;
+    constexpr int CHUNK = 64, HALF = 32, PER16 = 8;
+    constexpr int A_ITERS = (NPATCH * 4 + NTHR - 1) / NTHR;               // 6 (four 16-byte pieces per patch pixel and channel half)
+    constexpr int NBI = (BN * 64 + NTHR * 16 - 1) / (NTHR * 16);          // LDS-DMA pieces per thread and half K-step (BN 96: 2 -- rows 96 .. 127 of the second belong to the next cout tile, never read)
+    constexpr int H_BYTES = NBI * NTHR * 16, RING = 3;
+    constexpr int PITCH = 80;
+    constexpr int A_BASE = RING * H_BYTES, A_BYTES = NPATCH * PITCH;      // two patch buffers: A_BASE, A_BASE + A_BYTES
+    constexpr int RN_BASE = A_BASE + 2 * A_BYTES;
+    constexpr int CV_BASE = RN_BASE + (NPATCH * 4 + 15) / 16 * 16;
+    constexpr int NU = NT * 2;
+    static_assert(BN % 32 == 0 && BN <= NTHR, "tile shape");
+    static_assert((RING - 1) * H_BYTES + (NT - 1) * 2048 + 64 < 65536 && A_BYTES + 2 * PW * PITCH + 2 * PITCH + 64 < 65536, "ds_read offset field");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // the ONLY LDS object: its offset is 0
+    float* s_rn = (float*)(smem + RN_BASE);
+    float* s_cv = (float*)(smem + CV_BASE);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave;
+    const int l31 = lane & 31, lh = lane >> 5;
+#ifdef TD_TRACE
+    unsigned long long tr_wait = 0, tr_stage = 0;
+#endif
+    TDW_T(tr_start);
+#ifdef TD_TRACE
+    const unsigned long long tr_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    // workgroup-id decode: conv_glds.hip's (XCD-aware sibling order, alternating walk direction, magic-number divisions, one kernel-argument burst)
+    unsigned k_d1 = p.sb_d1, k_m1 = p.sb_m1, k_m2 = p.sb_m2, k_m3 = p.sb_m3, k_g8 = p.sb_grid8, k_grid = p.sb_grid;
+    int k_tx = p.tiles_x, k_ty = p.tiles_y, k_rev = p.reverse, k_cpad = p.CoutPad, k_N = p.N, k_H = p.H, k_W = p.W, k_nseg = p.nseg;
+    const unsigned char* k_wpack = (const unsigned char*)p.wpack;
+    int k_epi = p.epi, k_Cout = p.Cout, k_cvs = p.cvec_stride;
+    int k_c0 = p.seg[0].C, k_c1 = p.seg[1].C, k_c2 = p.seg[2].C, k_t0 = p.seg[0].taps, k_t1 = p.seg[1].taps, k_t2 = p.seg[2].taps;
+    const bool k_hres = p.res != nullptr;
+    asm volatile("" : "+s"(k_cpad), "+s"(k_N), "+s"(k_H), "+s"(k_W), "+s"(k_wpack), "+s"(k_epi), "+s"(k_Cout), "+s"(k_cvs), "+s"(k_nseg));
+    asm volatile("" : "+s"(k_d1), "+s"(k_m1), "+s"(k_m2), "+s"(k_m3), "+s"(k_g8), "+s"(k_grid), "+s"(k_tx), "+s"(k_ty), "+s"(k_rev), "+s"(k_c0), "+s"(k_c1), "+s"(k_c2), "+s"(k_t0), "+s"(k_t1), "+s"(k_t2));
+    unsigned ubid = blockIdx.x;
+    if (k_g8) ubid = (ubid & 7) * k_g8 + (ubid >> 3);
+    if (k_rev) ubid = k_grid - 1 - ubid;
+    const unsigned mtile = td_udiv(ubid, k_d1, k_m1);
+    const int ntile = (int)(ubid - mtile * k_d1);
+    const unsigned q2 = td_udiv(mtile, (unsigned)k_tx, k_m2);
+    const int txi = (int)(mtile - q2 * (unsigned)k_tx), ig = (int)td_udiv(q2, (unsigned)k_ty, k_m3), tyi = (int)(q2 - (unsigned)ig * (unsigned)k_ty);
+    const int n0 = ig, y0 = tyi * TH, x0 = txi * TW, co0 = ntile * BN;
+    // 64-channel units of the leading 3x3 segments (the host orders 3x3 segments before 1x1 segments), per segment and in all
+    const int u0 = k_t0 == 9 ? k_c0 / CHUNK : 0, u1 = (k_nseg > 1 && k_t0 == 9 && k_t1 == 9) ? k_c1 / CHUNK : 0, u2 = (k_nseg > 2 && u1 > 0 && k_t2 == 9) ? k_c2 / CHUNK : 0;
+    const int n3 = u0 + u1 + u2;
+
+    // ---- weight ring: half K-steps.  wnext = (SGPR) address of the K-step whose half is fetched next, wchunk = the first K-step (tap 0) of the 64-channel
+    // unit being fetched: a unit is 18 half tiles -- taps 0 .. 8 of channel half 0, then taps 0 .. 8 of half 1 (the same nine 128-byte rows per cout,
+    // `offset ^ 64`).  Every half-step fetches the half tile two half-steps ahead UNCONDITIONALLY (the slab carries two K-steps of tail padding).
+    const size_t wstep = (size_t)k_cpad * 128;
+    const unsigned char* wchunk = k_wpack + (size_t)co0 * 128;
+    const unsigned char* wnext = wchunk;
+    unsigned wvoff[NBI];
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+        const int pos = tid + i * NTHR, r = pos >> 2, j = (pos & 3) ^ ((r >> 2) & 3), x = TD_SWZ(r);
+        wvoff[i] = (unsigned)(r * 128 + ((((x & 4) | (j ^ (x & 3)))) << 4));
+    }
+    const unsigned ldsw = (unsigned)wave * 1024u;
+    // half tile T (0 .. 19; 18 / 19 = taps 0 / 1 of the NEXT unit) of the unit at wchunk into ring slot T % 3
+#define TDW_DMA(TILE)                                                                                        \
+    {                                                                                                        \
+        if ((TILE) == 9) wnext = wchunk;                                                                     \
+        if ((TILE) == 18) { wnext += wstep; wchunk = wnext; }                                                \
+        if ((TILE) >= 9 && (TILE) < 18) {                                                                    \
+            _Pragma("unroll") for (int i_ = 0; i_ < NBI; ++i_) { const unsigned v_ = wvoff[i_] ^ 64u; TD_GLDS16(v_, wnext, ldsw, ((TILE) % RING) * H_BYTES + i_ * NTHR * 16); } \
+        } else {                                                                                             \
+            _Pragma("unroll") for (int i_ = 0; i_ < NBI; ++i_) TD_GLDS16(wvoff[i_], wnext, ldsw, ((TILE) % RING) * H_BYTES + i_ * NTHR * 16); \
+        }                                                                                                    \
+        if ((TILE) != 8 && (TILE) != 17) wnext += wstep;                                                     \
+    }
+    TDW_DMA(0);
+    TDW_DMA(1);
+    const bool cv_stage = k_epi == EPI_EMB_SILU && tid < BN;
+    float cv_val = 0.f;
+    if (cv_stage) {
+        if (n0 < k_N && co0 + tid < k_Cout) cv_val = p.cvec[(size_t)n0 * k_cvs + co0 + tid];
+    }
+
+    // ---- activation-patch staging: 16-byte pieces (patch pixel e >> 2, piece e & 3 of the 32-channel half), one K-group ahead through registers,
+    // transformed on the way into LDS.  aoff = element offset of the thread's piece in the current segment's source, or -1 (zero fill).
+    u32x4 av[A_ITERS];
+    int aoff[A_ITERS];
+    const T* seg_src = nullptr;
+    int seg_taps = 9, seg_xform = 0, seg_nchunks = 0;
+    float seg_scale = 1.f;
+#define TDW_SEG_BEGIN(SEG)                                                                                            \
+    {                                                                                                                 \
+        const ConvSeg& sg_ = p.seg[SEG];                                                                              \
+        seg_src = (const T*)sg_.src; seg_taps = sg_.taps; seg_xform = sg_.xform; seg_scale = sg_.scale; seg_nchunks = sg_.C / CHUNK; \
+        const int Hs_ = sg_.Hs, Ws_ = sg_.Ws, rs_ = sg_.resample, cs_ = sg_.cstride;                                  \
+        _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) {                                                   \
+            int e_ = tid + it_ * NTHR;                                                                                \
+            asm volatile("" : "+v"(e_));   /* (the patch coordinates are re-derived per segment: nothing of them lives across the K loop) */ \
+            const int pp_ = e_ >> 2, py_ = pp_ / PW, px_ = pp_ - py_ * PW;                                            \
+            const int y_ = y0 + py_ - 1, x_ = x0 + px_ - 1;                                                           \
+            const bool ok_ = pp_ < NPATCH && n0 < k_N && y_ >= 0 && y_ < k_H && x_ >= 0 && x_ < k_W;                  \
+            const bool in_ = py_ >= 1 && py_ <= TH && px_ >= 1 && px_ <= TW;                                          \
+            aoff[it_] = -1;                                                                                           \
+            if (ok_ && (seg_taps == 9 || in_)) aoff[it_] = src_pixel(n0, y_, x_, Hs_, Ws_, rs_) * cs_ + (tid & 3) * PER16; \
+        }                                                                                                             \
+    }
+    // (always issued -- offset 0 for zero-fill pieces -- so that the vmcnt bookkeeping of the loop is exact)
+#define TDW_LOAD_A(CH, HF)                                                                             \
+    {                                                                                                  \
+        const T* src_ = seg_src + (CH) * CHUNK + (HF) * HALF;                                          \
+        _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) av[it_] = *(const u32x4*)(src_ + (aoff[it_] >= 0 ? aoff[it_] : 0)); \
+    }
+#define TDW_STORE_A(BUF)                                                                               \
+    {                                                                                                  \
+        _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) {                                    \
+            const int e_ = tid + it_ * NTHR, pp_ = e_ >> 2, slot_ = e_ & 3;                            \
+            if (pp_ < NPATCH) {                                                                        \
+                u32x4 v_ = aoff[it_] >= 0 ? av[it_] : u32x4{0u, 0u, 0u, 0u};                           \
+                if (TDW_XFORM_ON && seg_xform != 0 && aoff[it_] >= 0) {                                \
+                    float s_ = seg_scale;                                                              \
+                    if (seg_xform == 2) s_ *= s_rn[pp_];                                               \
+                    v_ = xform_piece<T>(v_, s_);                                                       \
+                }                                                                                      \
+                *(u32x4*)(smem + A_BASE + (BUF) * A_BYTES + pp_ * PITCH + (slot_ << 4)) = v_;          \
+            }                                                                                          \
+        }                                                                                              \
+    }
+    // residual runs of the wide epilogue: the first A_ITERS of the MT * NU units are requested during the LAST 3x3 unit into `av` (dead there), the rest
+    // at the top of the epilogue (conv_glds.hip round 5)
+    const bool r_want = k_epi == EPI_RESIDUAL && k_hres;
+    bool r_pref = false;
+    const T* r_ptr[MT];
+#define TDW_R_ADDR()                                                                                                  \
+    {                                                                                                                 \
+        const int rHs_ = p.res_Hs, rWs_ = p.res_Ws, rrs_ = p.res_resample, rcs_ = p.res_cstride;                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_) {                                                           \
+            int img_, ty_, tx_;                                                                                       \
+            frag_pixel<TW, TPIX>(wm * WM + i_ * 32, l31, img_, ty_, tx_);                                             \
+            const int y_ = y0 + ty_, x_ = x0 + tx_;                                                                   \
+            const int sp_ = (n0 < k_N && y_ < k_H && x_ < k_W) ? src_pixel(n0, y_, x_, rHs_, rWs_, rrs_) : 0;         \
+            r_ptr[i_] = (const T*)p.res + (sp_ * rcs_ + co0 + 8 * lh);                                                \
+        }                                                                                                             \
+    }
+#define TDW_R_UNIT(Q) (*(const u32x4*)(r_ptr[(Q) / NU] + ((co0 + (((Q) % NU) >> 1) * 32 < k_Cout) ? (((Q) % NU) >> 1) * 32 + ((Q) & 1) * 16 : 0)))
+#define TDW_LOAD_R()                                                                                                  \
+    {                                                                                                                 \
+        _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) av[it_] = TDW_R_UNIT(it_ < MT * NU ? it_ : MT * NU - 1); \
+        r_pref = true;                                                                                                \
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) r_ptr[i] = nullptr;
+    if (r_want) TDW_R_ADDR()
+    TDW_SEG_BEGIN(0);
+    TDW_LOAD_A(0, 0);
+
+    // ---- per-pixel 1/(eps + rms) of the pixel-normed source, for the patch pixels
+    const float* rn_sumsq = nullptr; int rn_parts = 0, rn_Hs = 0, rn_Ws = 0, rn_res = 0; float rn_invc = 0.f;
+    if (p.seg[0].xform == 2) { rn_sumsq = p.seg[0].sumsq; rn_parts = p.seg[0].nparts; rn_Hs = p.seg[0].Hs; rn_Ws = p.seg[0].Ws; rn_res = p.seg[0].resample; rn_invc = p.seg[0].inv_c; }
+    else if (p.res_sumsq) { rn_sumsq = p.res_sumsq; rn_parts = p.res_nparts; rn_Hs = p.res_Hs; rn_Ws = p.res_Ws; rn_res = p.res_resample; rn_invc = p.res_inv_c; }
+    if (rn_sumsq) {
+        const size_t npix = (size_t)p.N * rn_Hs * rn_Ws;
+        for (int pp = tid; pp < NPATCH; pp += NTHR) {
+            const int py = pp / PW, px = pp % PW;
+            const int y = y0 + py - 1, x = x0 + px - 1;
+            float rn = 0.f;
+            if (n0 < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W)
+                rn = pixel_rn(rn_sumsq, rn_parts, npix, src_pixel(n0, y, x, rn_Hs, rn_Ws, rn_res), rn_invc);
+            s_rn[pp] = rn;
+        }
+    }
+    if (cv_stage) s_cv[tid] = cv_val;
+
+    // ---- MFMA operand addressing: weights = A operand (rows = couts), activations = B operand (cols = pixels)
+    int base_pp[MT];
+    unsigned xbase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int img, ty, tx;
+        frag_pixel<TW, TPIX>(wm * WM + i * 32, l31, img, ty, tx);
+        base_pp[i] = (ty + 1) * PW + (tx + 1);
+        xbase[i] = (unsigned)A_BASE + (unsigned)(base_pp[i] - PW - 1) * PITCH + (unsigned)lh * 16u;
+    }
+    unsigned wbase[2];   // k-step (0 / 1) of the half: piece (2 ks + lh) ^ ((row >> 2) & 3) of this lane's row; the 32-row block j and the slot are compile-time
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) wbase[ks] = (unsigned)(l31 * 64 + (((ks * 2 + lh) ^ ((l31 >> 2) & 3)) << 4));
+    __syncthreads();  // s_rn visible
+    TDW_STORE_A(0);
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    TDW_T(tr_pro);
+
+#define TDW_TOFF(TP) ((((TP) / 3) * PW + ((TP) % 3)) * PITCH)
+    u32x4 wfA_[NT], xfA_[MT], wfB_[NT], xfB_[MT];
+    // fragments of k-step KS (0 / 1) of the half K-step in ring slot SLOT, patch buffer BUF, tap offset TOFF
+#define TDW_FRAG_READ(WF, XF, SLOT, KS, BUF, TOFF)                                                           \
+    {                                                                                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) WF[j_] = *(const u32x4*)(smem + wbase[KS] + ((SLOT) * H_BYTES + j_ * 2048)); \
+        _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_) XF[i_] = *(const u32x4*)(smem + xbase[i_] + ((BUF) * A_BYTES + (TOFF) + (KS) * 32)); \
+    }
+#define TDW_FRAG_MFMA(WF, XF)                                                                                \
+    {                                                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                                    \
+            _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                \
+                acc[i_][j_] = Half<T>::mfma32(__builtin_bit_cast(hx8, WF[j_]), __builtin_bit_cast(hx8, XF[i_]), acc[i_][j_]); \
+    }
+    // One half K-step S (0 .. 17) of a 64-channel unit: channel half S / 9 (= patch buffer), tap S % 9, ring slot S % 3; its fragments were requested
+    // during the previous half-step.  Passing its barrier: half tile S + 1 is visible (every wave waited for its own pieces), nobody reads half tile
+    // S - 1 any more (its slot takes S + 2), and the patch written two half-steps ago is visible.
+    //   S = 0: the patch of channel half 1 of this unit is requested (always exists); pinned at S = 2 (the loads are complete there: see the waits),
+    //          written into buffer 1 at S = 5 (its last readers -- the previous unit's half-steps 9 .. 17 -- passed this unit's barrier 1);
+    //   S = 9: the patch of half 0 of the NEXT unit (same segment, or the next 3x3 segment: `nxt` / `newseg`), written into buffer 0 at S = 14;
+    //   S = 17 requests the first fragments of the next unit (slot 0, buffer 0).
+    // Waits: in flight at the barrier of S are the pieces of S + 1 (issued one half-step ago) and, younger, the patch loads (issued at S - 1 = 0 / 9:
+    // counted past; complete one step later) or, in the last unit, the residual runs (issued at S = 15: counted past at 16; S = 17 needs nothing that
+    // was issued after tile 17 -- tile 18 belongs to a unit that does not exist).
+#define TDW_HS(S)                                                                                            \
+    {                                                                                                        \
+        TDW_T(tA_);                                                                                          \
+        if ((S) == 1 || ((S) == 10 && nxt)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS) : "memory");   \
+        else if ((S) == 16 && r_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS) : "memory");          \
+        else if ((S) == 17 && r_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS + NBI) : "memory");    \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+        if ((S) == 6 || (S) == 15) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* this wave's patch writes of the previous half-step are out */ \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        asm volatile("" ::: "memory");                                                                       \
+        TDW_T(tB_); TDW_TACC(tr_wait, tA_, tB_);                                                             \
+        if ((S) == 2 || ((S) == 11 && nxt)) {                                                                \
+            _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) asm volatile("" : "+v"(av[it_]));      \
+        }                                                                                                    \
+        TDW_DMA((S) + 2);                                                                                    \
+        if ((S) == 0) TDW_LOAD_A(chunk, 1);                                                                  \
+        if ((S) == 9 && nxt) { if (newseg) TDW_SEG_BEGIN(seg + 1); TDW_LOAD_A(newseg ? 0 : chunk + 1, 0); }  \
+        if ((S) == 15 && r_now) TDW_LOAD_R()                                                                 \
+        if ((S) == 5) TDW_STORE_A(1);                                                                        \
+        if ((S) == 14 && nxt) TDW_STORE_A(0);                                                                \
+        TDW_FRAG_MFMA(wfA_, xfA_);                                                                           \
+        if ((S) < 17 || nxt) TDW_FRAG_READ(wfA_, xfA_, ((S) + 1) % RING, 0, (((S) + 1) / 9) & 1, TDW_TOFF(((S) + 1) % 9)); \
+        TDW_FRAG_MFMA(wfB_, xfB_);                                                                           \
+        if ((S) < 17 || nxt) TDW_FRAG_READ(wfB_, xfB_, ((S) + 1) % RING, 1, (((S) + 1) / 9) & 1, TDW_TOFF(((S) + 1) % 9)); \
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);                                             \
+    }
+    int seg = 0, chunk = 0;
+    if (n3 > 0) {
+        // entry of the pipeline: this wave's patch writes are out, half tiles 0 and 1 were issued a prologue ago
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        TDW_FRAG_READ(wfA_, xfA_, 0, 0, 0, TDW_TOFF(0));
+        TDW_FRAG_READ(wfB_, xfB_, 0, 1, 0, TDW_TOFF(0));
+        for (int u = 0; u < n3; ++u) {
+            const bool nxt = u + 1 < n3;
+            const bool newseg = nxt && chunk + 1 == seg_nchunks;
+            const bool r_now = r_want && !nxt && n3 == p.kgroups;   // last unit of a launch without a 1x1 tail
+            TDW_HS(0); TDW_HS(1); TDW_HS(2); TDW_HS(3); TDW_HS(4); TDW_HS(5); TDW_HS(6); TDW_HS(7); TDW_HS(8);
+            TDW_HS(9); TDW_HS(10); TDW_HS(11); TDW_HS(12); TDW_HS(13); TDW_HS(14); TDW_HS(15); TDW_HS(16); TDW_HS(17);
+            if (newseg) { ++seg; chunk = 0; } else ++chunk;
+        }
+    }
+    // ---- 1x1 tail (the fused skip conv of the decoder's conv_res1, pure 1x1 convs): centre tap, one half K-step per (chunk, channel half), NOT pipelined --
+    // each half-step fetches its own patch and half tile.  Correct and slow (two barriers and a memory round trip per 12 MFMAs of a wave): the planner
+    // keeps launches with a long 1x1 tail on conv_glds.hip, whose LDS-DMA stream serves them.
+#ifndef TDW_NO_TAIL
+    if (n3 < p.kgroups) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two half tiles fetched past the end of the 3x3 part
+        const unsigned char* w1 = k_wpack + (size_t)co0 * 128 + (size_t)n3 * 9 * wstep;
+        int s1 = n3 == 0 ? 0 : (chunk == 0 && seg > 0 ? seg : seg + 1);
+        if (n3 > 0 && !(chunk == 0 && seg > 0)) s1 = seg + 1;
+        if (n3 == 0) s1 = 0;
+        for (int sg = s1; sg < k_nseg; ++sg) {
+            TDW_SEG_BEGIN(sg);
+            for (int ch = 0; ch < seg_nchunks; ++ch, w1 += wstep) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    TDW_LOAD_A(ch, hf);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();   // every wave is done with patch buffer 0 and ring slot 0
+                    asm volatile("" ::: "memory");
+                    TDW_STORE_A(0);
+#pragma unroll
+                    for (int i_ = 0; i_ < NBI; ++i_) { const unsigned v_ = hf ? (wvoff[i_] ^ 64u) : wvoff[i_]; TD_GLDS16(v_, w1, ldsw, i_ * NTHR * 16); }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    TDW_FRAG_READ(wfA_, xfA_, 0, 0, 0, TDW_TOFF(4));
+                    TDW_FRAG_READ(wfB_, xfB_, 0, 1, 0, TDW_TOFF(4));
+                    TDW_FRAG_MFMA(wfA_, xfA_);
+                    TDW_FRAG_MFMA(wfB_, xfB_);
+                }
+            }
+        }
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-fetched tail tiles must not land in a successor's LDS
+#undef TDW_TOFF
+#undef TDW_HS
+#undef TDW_FRAG_READ
+#undef TDW_FRAG_MFMA
+#undef TDW_LOAD_A
+#undef TDW_STORE_A
+#undef TDW_SEG_BEGIN
+#undef TDW_DMA
+
+    TDW_T(tr_loop);
+    // ---------------- epilogue (conv_glds.hip's wide / narrow paths; no split-K here)
+    int e_Cout = p.Cout, e_epi = p.epi, e_ocs = p.out_cstride;
+    float e_rsc = p.res_scale, e_clip = p.clip, e_o2s = p.out2_scale;
+    const bool e_hres = p.res != nullptr, e_hrss = p.res_sumsq != nullptr, e_hoss = p.out_sumsq != nullptr, e_ho2 = p.out2 != nullptr;
+    asm volatile("" : "+s"(e_Cout), "+s"(e_epi), "+s"(e_ocs), "+s"(e_rsc), "+s"(e_clip), "+s"(e_o2s));
+    const size_t M = (size_t)k_N * k_H * k_W;
+    // (bf16 / fp16 output with Cout % 8 == 0 only -- the dwordx4 store path; the launcher refuses everything else: fp32 outputs and the solver-step epilogue
+    // of the few-channel output convs stay on conv_glds.hip)
+    const bool has_res = e_epi == EPI_RESIDUAL && e_hres;
+    constexpr int NRX = MT * NU > A_ITERS ? MT * NU - A_ITERS : 1;
+    u32x4 rx[NRX];
+#pragma unroll
+    for (int q = 0; q < NRX; ++q) rx[q] = u32x4{0u, 0u, 0u, 0u};
+    if (has_res) {
+        if (!r_pref) TDW_LOAD_R()   // the launch ended in 1x1 K-groups: nothing was requested yet
+        if constexpr (MT * NU > A_ITERS) {
+#pragma unroll
+            for (int q = 0; q < NRX; ++q) rx[q] = TDW_R_UNIT(A_ITERS + q);
+        }
+    }
+    // (one instance per 32-pixel row group, by hand: left to `#pragma unroll` the loop stayed rolled -- hipcc gave up on its size -- and the accumulators,
+    // the prefetched residual runs and `rx` were then indexed by a run-time `i`, i.e. lived in scratch memory for the WHOLE kernel)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        {
+        int img, ty, tx;
+        frag_pixel<TW, TPIX>(wm * WM + i * 32, l31, img, ty, tx);
+        const int n = n0, y = y0 + ty, x = x0 + tx;
+        const bool ok = n < k_N && y < k_H && x < k_W;
+        float ssj[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) ssj[j] = 0.f;
+        if (ok) {
+            const float rn = e_hrss ? s_rn[base_pp[i]] : 1.f;
+            {
+                const size_t pix = ((size_t)n * k_H + y) * k_W + x;
+                T* orow = (T*)p.out + pix * e_ocs + co0 + 8 * lh;
+                const float rs = e_rsc * rn;
+                const bool want_ss = e_hoss, want_o2 = e_ho2;
+                const SiluK k_o2 = silu_k(e_o2s);
+                auto body = [&](auto KIND) __attribute__((always_inline)) {
+                    constexpr int K = decltype(KIND)::value;
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int j = u >> 1, m = u & 1;
+                        f32x4 ca = {0.f, 0.f, 0.f, 0.f}, cb = ca;
+                        u32x4 rw = {0u, 0u, 0u, 0u};
+                        if constexpr (K == 1) {
+                            const float* c_ = s_cv + (u >> 1) * 32 + (u & 1) * 16 + 4 * lh;
+                            ca = *(const f32x4*)c_; cb = *(const f32x4*)(c_ + 8);
+                        }
+                        if constexpr (K == 2) rw = i * NU + u < A_ITERS ? av[i * NU + u < A_ITERS ? i * NU + u : 0] : rx[i * NU + u >= A_ITERS ? i * NU + u - A_ITERS : 0];
+                        if (co0 + j * 32 >= e_Cout) continue;
+                        const f32x4 va = {acc[i][j][8 * m + 0], acc[i][j][8 * m + 1], acc[i][j][8 * m + 2], acc[i][j][8 * m + 3]};
+                        const f32x4 vb = {acc[i][j][8 * m + 4], acc[i][j][8 * m + 5], acc[i][j][8 * m + 6], acc[i][j][8 * m + 7]};
+                        u32x4 o, o2;
+                        epi_unit8<T>(e_epi, has_res, e_clip, want_ss, want_o2, va, vb, ca, cb, rw, rs, k_o2, o, o2, ssj[j]);
+                        *(u32x4*)(orow + j * 32 + m * 16) = o;
+                        if (want_o2) *(u32x4*)((T*)p.out2 + (orow - (T*)p.out) + j * 32 + m * 16) = o2;
+                    }
+                };
+                if (e_epi == EPI_EMB_SILU) body(std::integral_constant<int, 1>{});
+                else if (has_res) body(std::integral_constant<int, 2>{});
+                else body(std::integral_constant<int, 0>{});
+            }
+        }
+        if (e_hoss) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float ss = ssj[j] + __shfl_xor(ssj[j], 32);
+                if (ok && lh == 0 && co0 + j * 32 < k_cpad) {
+                    const size_t pix = ((size_t)n * k_H + y) * k_W + x;
+                    p.out_sumsq[(size_t)(co0 / 32 + j) * M + pix] = ss;
+                }
+            }
+        }
+        }
+    }
+#ifdef TD_TRACE
+    TDW_T(tr_eissue);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TDW_T(tr_end);
+    if (lane == 0) {
+        unsigned long long* tb = (unsigned long long*)p.partial + ((size_t)blockIdx.x * 4 + wave) * 16;
+        tb[0] = tr_pro - tr_start; tb[1] = tr_loop - tr_pro; tb[2] = tr_end - tr_loop; tb[3] = tr_wait; tb[4] = tr_stage; tb[5] = tr_start; tb[6] = tr_end;
+        tb[8] = tr_rt0; tb[9] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8) | __builtin_amdgcn_s_getreg((3 << 11) | 20);
+        tb[10] = __builtin_amdgcn_s_memrealtime();
+        tb[7] = tb[10] - tr_rt0; tb[11] = tr_end - tr_eissue;
+    }
+#endif
+#undef TDW_R_ADDR
+#undef TDW_R_UNIT
+#undef TDW_LOAD_R
+}
+
+template <typename T, int BN>
+static hipError_t launch_glds_wide_cfg(const ConvParams& p, hipStream_t st) {
+    constexpr int NPATCH = 18 * 18;
+    constexpr size_t RING_BYTES = 3 * (size_t)(((BN * 64 + 4095) / 4096) * 4096);
+    constexpr size_t LDS = RING_BYTES + 2 * (size_t)NPATCH * 80 + (NPATCH * 4 + 15) / 16 * 16 + (size_t)BN * 4;
+    if (p.ksplit != 1 || p.W < 16 || p.CoutPad % BN || p.nseg < 1 || p.nseg > 3) return hipErrorInvalidValue;
+    if (p.out_f32 || (p.Cout & 7) || p.epi == EPI_DPM_STEP) return hipErrorInvalidValue;   // the 16-byte-run epilogue only
+    bool seen1 = false;   // 3x3 segments first
+    for (int s = 0; s < p.nseg; ++s) { if (p.seg[s].taps == 9 && seen1) return hipErrorInvalidValue; if (p.seg[s].taps != 9) seen1 = true; }
+    ConvParams pd = p;
+    for (int s = p.nseg; s < 3; ++s) { pd.seg[s].C = 0; pd.seg[s].taps = 0; }   // (the kernel reads all three descriptors in one burst)
+    const int mtiles = p.tiles_x * p.tiles_y * p.img_groups, grid = p.n_ntiles * mtiles;
+    if (grid <= 0 || (long long)grid * std::max(mtiles, p.n_ntiles) >= ((long long)1 << 32)) return hipErrorInvalidValue;
+    pd.sb_d0 = mtiles; pd.sb_m0 = td_magic(mtiles); pd.sb_d1 = p.n_ntiles; pd.sb_m1 = td_magic(p.n_ntiles); pd.sb_m2 = td_magic(p.tiles_x); pd.sb_m3 = td_magic(p.tiles_y);
+    pd.sb_grid = grid; pd.sb_grid8 = (grid & 7) == 0 ? (unsigned)grid >> 3 : 0u;
+    auto kern = conv_glds_kernel_wide<T, BN>;
+    static bool attr_set[64] = {};
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) return e;
+        if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, pd);
+    return hipGetLastError();
+}
+
+// dtype: 1 bf16, 2 fp16; bn: 64 / 96 / 128.  16-wide maps only, tiles_y = ceil(H / 16), tiles_x = ceil(W / 16), img_groups = N, no split-K.
+hipError_t launch_conv_glds_wide(const ConvParams& p, int dtype, int bn, hipStream_t st) {
+#ifdef TDW_ONLY96   // (development builds: one instantiation)
+    return dtype == 1 && bn == 96 ? launch_glds_wide_cfg<__bf16, 96>(p, st) : hipErrorInvalidValue;
+#endif
+    if (dtype == 2) {
+        if (bn == 96) return launch_glds_wide_cfg<_Float16, 96>(p, st);
+        if (bn == 128) return launch_glds_wide_cfg<_Float16, 128>(p, st);
+        if (bn == 64) return launch_glds_wide_cfg<_Float16, 64>(p, st);
+        return hipErrorInvalidValue;
+    }
+    if (bn == 96) return launch_glds_wide_cfg<__bf16, 96>(p, st);
+    if (bn == 128) return launch_glds_wide_cfg<__bf16, 128>(p, st);
+    if (bn == 64) return launch_glds_wide_cfg<__bf16, 64>(p, st);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace td

@@ -17,6 +17,7 @@
 // single translation unit: kernels are compiled together with the host runtime
 #include "conv_igemm.hip"
 #include "conv_glds.hip"
+#include "conv_glds_wide.hip"
 #include "conv_sb.hip"
 #include "conv_s16.hip"
 #include "small_kernels.hip"
@@ -164,6 +165,7 @@ struct td_engine {
     hipStream_t stream = nullptr;   // the stream every call enqueues on: the engine's own, or the caller's (td_engine_set_stream)
     hipStream_t own_stream = nullptr;
     hipStream_t stream2 = nullptr;  // second lane of the batched EDM sampler (sample_edm_impl): two half-batches run concurrently
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // its ordering against the first lane's stream (which may be the caller's)
     std::vector<std::unique_ptr<struct DevBuf>> deferred;  // option "async": staging buffers of enqueued calls, released by td_engine_synchronize
     std::map<std::string, int64_t> opt;
     // scratch for I/O staging
@@ -672,7 +674,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
     static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn",
                                                "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
                                                "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups", "glds_round_aware", "walk_alternate", "glds_tiny", "glds_dma1x1", "splitk_weighted",
-                                               "sb", "sb_target_wgs", "sb_mt", "sb_nt", "sb_order", "sb_max_glds_wgs", "sb_splitk", "sb_splitk_wgs", "sb_splitk_max", "s16", "s16_min_wgs", "sb_m4"};
+                                               "sb", "sb_target_wgs", "sb_mt", "sb_nt", "sb_order", "sb_max_glds_wgs", "sb_splitk", "sb_splitk_wgs", "sb_splitk_max", "s16", "s16_min_wgs", "sb_m4", "glds_wide", "glds_wide_min_wgs"};
     std::string key = std::to_string(N) + "_" + std::to_string(H) + "_" + std::to_string(W);
     for (const char* o : kPlanOptions) key += "_" + std::to_string((long long)u->eng->option(o, -7));
     if (lane) key += "_lane" + std::to_string(lane);   // a second, independent activation set of the same shape (concurrent half-batches)
@@ -817,6 +819,24 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                         p.ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(kgroups, u->eng->option("glds_splitk_max", 32)), 384 / wgs_tiny));
                     }
                 }
+                // Wide tile (conv_glds_wide.hip, round 6): 256 px x 96 / 64 couts on 4 waves, two workgroups per CU, 32-channel K-groups with a double-buffered
+                // patch -- half the weight bytes per MFMA through the CU's L2 -> LDS path, 0.6x the LDS fragment reads, half as many workgroup
+                // prologues / epilogue drains, no restage barrier.  Taken where its grid still gives every CU slot >= "glds_wide_min_wgs" / 512 workgroups
+                // (the 64x64 and 32x32 levels of a 64-window batch, the decoder's 512x512 / 256x256 levels) for launches it serves at full speed: pure
+                // 3x3 K (its 1x1 tail is not pipelined), 16-bit output in 16-byte runs.  Another K order than the other tiles (channel half outside the
+                // taps): never in batch_invariant mode, where the choice must not depend on the batch.  Option "glds_wide": 0 never, 1 this rule, 2 wherever legal.
+                {
+                    const int64_t wmode = u->eng->option("glds_wide", 1);
+                    bool pure3 = true;
+                    for (const SegSpec& sg : segs) if (sg.taps != 9) pure3 = false;
+                    const int bnw = cw.cout_pad % 96 == 0 ? 96 : (cw.cout_pad % 64 == 0 ? 64 : 0);
+                    const int64_t wgs_w = bnw ? tiles(16, 1) * (cw.cout_pad / bnw) : 0;
+                    if (wmode != 0 && !inv && fv < 0 && fbn == 0 && !op.narrow && p.ksplit == 1 && bnw && !out_f32 && (cw.cout & 7) == 0 && p.nseg <= 3 && (pure3 || wmode == 2) &&
+                        (wmode == 2 || wgs_w >= u->eng->option("glds_wide_min_wgs", 1024))) {
+                        op.glds_variant = 3; op.bn = bnw;
+                        p.tiles_x = (w + 15) / 16; p.tiles_y = (h + 15) / 16; p.img_groups = N; p.n_ntiles = cw.cout_pad / bnw;
+                    }
+                }
                 // Small-batch flavour (conv_sb.hip, round 4) wherever the throughput tiles do not fill the chip (workgroups x 2 <= CU slots: the
                 // launches that used to split K over WORKGROUPS).  K is split over the four waves of a workgroup and reduced through LDS: no fp32
                 // partial planes in HBM, no reduce launch (BASELINE configs[1]: one tile x 20 steps; the 1-16-window batches of the cascade's latent
@@ -825,7 +845,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                 // additionally split K over workgroups, 64 x 32 tiles, ~224 workgroups in all: the partial planes there are small (64 - 256 pixels)
                 // and the reduce launch costs less than the weight stream gains (tools/sb_splitk.sh: 8x8 1536->768 39 -> 17 us cold).
                 // Not in batch_invariant mode (conv_glds stays pinned): the K order differs, so the choice must not depend on the batch.
-                if (op.flavor == 2 && sb_takes) {
+                if (op.flavor == 2 && sb_takes && op.glds_variant != 3) {
                     {
                         const int TWs = op.narrow ? 8 : 16;
                         auto th_of = [&](int mt) { return op.narrow ? (mt == 2 ? 8 : 4) : (mt == 4 ? 8 : mt == 2 ? 4 : 2); };
@@ -1165,7 +1185,8 @@ static int run_unet(td_unet* u, Plan& pl, int step, const SchedCoef* fuse = null
         mark();
         hipError_t e = op.flavor == 5 ? launch_conv_s16(p, u->dt, op.narrow, st)
                        : op.flavor == 4 ? launch_conv_sb(p, u->dt, op.narrow, op.sb_mt, op.sb_nt, st)
-                       : op.flavor == 2 ? launch_conv_glds(p, u->dt, op.narrow, op.bn, op.glds_variant, st) : launch_conv(p, u->dt, op.narrow, op.bn, 0, st);
+                       : op.flavor == 2 ? (op.glds_variant == 3 ? launch_conv_glds_wide(p, u->dt, op.bn, st) : launch_conv_glds(p, u->dt, op.narrow, op.bn, op.glds_variant, st))
+                       : launch_conv(p, u->dt, op.narrow, op.bn, 0, st);
         mark(); if (prof) { ev_kind.push_back(0); char tag[160]; double gf_ = op.k_alg * 2.0 * p.N * p.H * p.W * p.Cout * 1e-9;  /* algorithmic GFLOP of this launch: REAL input channels (the 6-channel input conv is 5.4 GFLOP at batch 64, not the 58 its K padding to 64 would give) */
             /* algorithmic HBM megabytes of this launch: every source tensor once (at ITS resolution), the residual once, the outputs once, the weights once */
             double mb_ = 0.0; const double es_ = (double)u->esize();
@@ -1175,7 +1196,7 @@ static int run_unet(td_unet* u, Plan& pl, int step, const SchedCoef* fuse = null
             const double mbs_ = (mb_ + o1_) * 1e-6;   /* strict: without the optional pre-activated second output (an optimisation, not part of the layer's definition) */
             mb_ += o1_ * (p.out2 ? 2.0 : 1.0);
             mb_ *= 1e-6;
-            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f mb%.2f mbs%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 5 ? "c16" : op.flavor == 4 ? (op.sb_mt == 4 ? "m4n1" : op.sb_mt == 2 ? (op.sb_nt == 2 ? "m2n2" : "m2n1") : (op.sb_nt == 2 ? "m1n2" : "m1n1")) : op.flavor == 2 ? (op.glds_variant == 2 ? "t" : op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_, mb_, mbs_); ev_label.push_back(op.label + tag);
+            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f mb%.2f mbs%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 5 ? "c16" : op.flavor == 4 ? (op.sb_mt == 4 ? "m4n1" : op.sb_mt == 2 ? (op.sb_nt == 2 ? "m2n2" : "m2n1") : (op.sb_nt == 2 ? "m1n2" : "m1n1")) : op.flavor == 2 ? (op.glds_variant == 3 ? "w" : op.glds_variant == 2 ? "t" : op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_, mb_, mbs_); ev_label.push_back(op.label + tag);
             ev_flop.push_back(op.flavor == 2 ? 2.0 * p.N * p.H * p.W * (double)p.Cout * op.k_alg : 0.0); }   // the LDS-DMA family alone (bench.py's roofline kernel); small-batch launches are told apart by their f4 label
         if (e != hipSuccess) return fail(TD_ERR_HIP, "conv launch " + op.label + ": " + hipGetErrorString(e));
     }
@@ -1206,10 +1227,12 @@ int td_engine_create(int device_id, td_engine** out) {
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     e->own_stream = e->stream;
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
     if (err == hipSuccess) err = hipMalloc(&e->zeros, 4096);
     if (err == hipSuccess) err = hipMemset(e->zeros, 0, 4096);
     if (err == hipSuccess) err = hipDeviceSynchronize();
-    if (err != hipSuccess) { if (e->stream) (void)hipStreamDestroy(e->stream); if (e->stream2) (void)hipStreamDestroy(e->stream2); delete e; return fail(TD_ERR_HIP, hipGetErrorString(err)); }
+    if (err != hipSuccess) { if (e->stream) (void)hipStreamDestroy(e->stream); if (e->stream2) (void)hipStreamDestroy(e->stream2); if (e->ev_fork) (void)hipEventDestroy(e->ev_fork); if (e->ev_join) (void)hipEventDestroy(e->ev_join); delete e; return fail(TD_ERR_HIP, hipGetErrorString(err)); }
     *out = e;
     return TD_OK;
 }
@@ -1218,6 +1241,8 @@ void td_engine_destroy(td_engine* e) {
     DevGuard dg_(e->device);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->stream2) (void)hipStreamDestroy(e->stream2);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->zeros) (void)hipFree(e->zeros);
     delete e;
 }
@@ -1241,7 +1266,7 @@ static const char* const kKnownOptions[] = {
     "plan_cache_mb", "plan_cache_max",
     // plan builder (speed only, or test hooks that force a tile shape; all part of the plan-cache key)
     "attn_mfma", "bn128_min_wgs", "glds", "glds_bn", "glds_bn64", "glds_dma1x1", "glds_min_wgs", "glds_round_aware", "glds_small_max_groups",
-    "glds_splitk", "glds_splitk_from_groups", "glds_splitk_max", "glds_splitk_min_groups", "glds_tiny", "glds_variant",
+    "glds_splitk", "glds_splitk_from_groups", "glds_splitk_max", "glds_splitk_min_groups", "glds_tiny", "glds_variant", "glds_wide", "glds_wide_min_wgs",
     "producer_act", "s16", "s16_min_wgs", "sb", "sb_m4", "sb_max_glds_wgs", "sb_mt", "sb_nt", "sb_order", "sb_splitk", "sb_splitk_max", "sb_splitk_wgs", "sb_target_wgs", "splitk",
     "splitk_target_wgs", "splitk_weighted", "walk_alternate"};
 int td_engine_set_option(td_engine* e, const char* key, int64_t value) {
@@ -1562,26 +1587,33 @@ static int sample_edm_lane(td_unet* u, td_unet* guide, float gscale, int n, int 
     return TD_OK;
 }
 
-// Engine option "dual_stream" (default 0; +2.3 % on the 8x8-grid bench, +3.1 % on independent tiles, A/B on one box, profiles/r02_dual_stream_ab.txt):
+// Engine option "dual_stream" (default 1 since round 6: +4.9 ... +5.1 % on the 8x8-grid bench in both A/B orders, +4.5 % on the 32x32 grid,
+// profiles/r06_dual_stream_ab.txt; +2.3 % in round 2, profiles/r02_dual_stream_ab.txt):
 // batches of >= "dual_stream_min_batch" tiles (default 32) run as TWO independent half-batches on two streams: tiles are independent, and a
 // kernel whose grid does not fill a whole number of rounds of the 256 CUs (768 workgroups on 512 slots at the 16x16 level of a 64-tile
 // batch: 1.5 rounds), its launch gap and its epilogue tail leave CUs idle that the other lane's kernels fill.  Every window's arithmetic is
-// the same as in one batch (tile shapes are bit-identical); only split-K layers may differ in rounding -- batch_invariant mode has none.
+// that of a half-size batch: the plan of a 32-window batch differs from a 64-window batch's in the layers whose tile / flavour / split-K choice
+// depends on the grid size (1.6e-3 rel-RMS on the blended configs[2] canvas, bf16); batch_invariant mode pins those choices and gives the same bits.
+// The second lane's stream is ordered behind the first lane's at entry (inputs produced on the engine's stream -- the caller's, with
+// td_engine_set_stream -- are complete before lane two reads them) and the first lane's stream waits for the second at the end, so that the call ends
+// like a single-lane one: results ordered on the engine's stream, enqueue-only under option "async".
 static int sample_edm_impl(td_unet* u, td_unet* guide, float gscale, int n, int H, int W, int n_steps, const float* sigmas_host, float sigma_data,
                            const float* cond, const float* cond_img, int cimg, float* x) {
     td_engine* e = u->eng;
     DevGuard dg_(e->device);
     std::vector<Buf> hold;
-    const bool dual = e->stream2 && e->option("dual_stream", 0) != 0 && n >= std::max<int64_t>(2, e->option("dual_stream_min_batch", 32));
+    const bool dual = e->stream2 && e->option("dual_stream", 1) != 0 && n >= std::max<int64_t>(2, e->option("dual_stream_min_batch", 32));
     const bool concurrent = e->option("profile", 0) == 0;  // profile mode times every launch with events on ONE stream: the lanes run one after the other
+    const bool all_dev = is_device_ptr(x) && (!cond || is_device_ptr(cond)) && (!cond_img || is_device_ptr(cond_img));
     if (!dual) {
         int rc = sample_edm_lane(u, guide, gscale, n, H, W, n_steps, sigmas_host, sigma_data, cond, cond_img, cimg, x, 0, hold);
         if (rc) { (void)hipStreamSynchronize(e->stream); return rc; }
         // default: results complete on return (the caller's framework uses other streams); option "async": left enqueued on e->stream
-        return end_call(e, hold, is_device_ptr(x) && (!cond || is_device_ptr(cond)) && (!cond_img || is_device_ptr(cond_img)));
+        return end_call(e, hold, all_dev);
     }
     const int nA = n / 2, nB = n - nA, C = u->cfg.out_channels;
     const size_t HW = (size_t)H * W;
+    if (concurrent) { HIP_TRY(hipEventRecord(e->ev_fork, e->stream)); HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_fork, 0)); }
     int rc = sample_edm_lane(u, guide, gscale, nA, H, W, n_steps, sigmas_host, sigma_data, cond, cond_img, cimg, x, 0, hold);
     if (!rc) {
         if (concurrent) std::swap(e->stream, e->stream2);
@@ -1589,10 +1621,9 @@ static int sample_edm_impl(td_unet* u, td_unet* guide, float gscale, int n, int 
                              cond_img ? cond_img + (size_t)nA * cimg * HW : nullptr, cimg, x + (size_t)nA * C * HW, 1, hold);
         if (concurrent) std::swap(e->stream, e->stream2);
     }
-    hipError_t s1 = hipStreamSynchronize(e->stream), s2 = hipStreamSynchronize(e->stream2);
-    if (rc) return rc;
-    HIP_TRY(s1); HIP_TRY(s2);
-    return TD_OK;
+    if (rc) { (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream2); return rc; }
+    if (concurrent) { HIP_TRY(hipEventRecord(e->ev_join, e->stream2)); HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join, 0)); }
+    return end_call(e, hold, all_dev);
 }
 
 int td_sample_edm_img(td_unet* u, int n, int H, int W, int n_steps, const float* sigmas_host, float sigma_data, const float* cond,

@@ -81,10 +81,12 @@ def _forward_with(eng, m, x, t, c, n, **opts):
     try:
         # the arms of these tests compare tile shapes of the LDS-DMA conv (conv_glds): the small-batch flavour (round 4, conv_sb.hip -- its own tile
         # hooks are sb_mt / sb_nt, tests/test_gpu_small_batch.py) would otherwise take the small grids of a batch <= 8 whatever the glds_* hooks say
-        opts = dict(opts, sb=opts.get("sb", 0))
+        # (and the wide tile of round 6, conv_glds_wide.hip -- another K order, compared with a tolerance in test_wide_tile_*  -- would take the 64x64 /
+        # 32x32 levels of a 64-window batch)
+        opts = dict(opts, sb=opts.get("sb", 0), glds_wide=opts.get("glds_wide", 0))
         for k, v in opts.items():
             eng.set_option(k, v)
-            prev[k] = {"glds_variant": -1, "glds_bn": 0, "glds_splitk": 1, "glds_dma1x1": 1, "sb": 1}[k]
+            prev[k] = {"glds_variant": -1, "glds_bn": 0, "glds_splitk": 1, "glds_dma1x1": 1, "sb": 1, "glds_wide": 1}[k]
         eng.set_option("profile", 1)
         eng.profile_read(reset=True)
         y = m(x, t, [c])
@@ -129,6 +131,55 @@ def test_conv_tile_variants_bit_identical(td, base, n):
             how = [q for q in labels if q.startswith(l + " ")] + [q for q in res["auto"][2] if q.startswith(l + " ")]
             assert torch.equal(acts[l], a0[l]), (k, l, float((acts[l] - a0[l]).abs().max()), how)
         assert torch.equal(y, y0), (k, float((y - y0).abs().max()))
+
+
+@pytest.mark.parametrize("n,hw", [(64, 64), (5, 72)])
+def test_wide_tile_against_the_other_tiles_and_the_oracle(td, base, n, hw):
+    """Round 6: the wide tile of the LDS-DMA conv (conv_glds_wide.hip: 256 px x 96 / 64 couts, 4 waves, 32-channel K-groups, double-buffered patch).  Its K
+    order differs from the other tiles' (channel half outside the taps), so it is compared with a tolerance, not bit for bit: the planner's choice
+    (64x64 / 32x32 levels of a 64-window batch) and the tile forced wherever it is legal (option glds_wide = 2: also the launches with a 1x1 tail, the
+    16x16 level, ragged 72 -> 36 -> 18 maps whose 16x16 tiles hang over the edge) against the network without it -- eight layers spread over the levels
+    and the output -- and sample 0 against the oracle at the bf16 bound."""
+    from terrain_diffusion_amd.engine import get_engine
+    from oracle import rng
+    m, om = base
+    eng = get_engine("cuda")
+    x = torch.from_numpy(rng.standard_normal(41, (n, 5, hw, hw))).cuda()
+    c = torch.from_numpy(rng.standard_normal(42, (n, 58))).cuda()
+    t = torch.full((n,), 0.7)
+    res = {}
+    for k, o in {"off": dict(glds_wide=0, sb=1), "auto": dict(glds_wide=1, sb=1), "force": dict(glds_wide=2, sb=1)}.items():
+        if hw == 64:
+            res[k] = _forward_with(eng, m, x, t, c, n, **o)
+        else:
+            try:
+                for kk, v in o.items():
+                    eng.set_option(kk, v)
+                eng.set_option("profile", 1); eng.profile_read(reset=True)
+                y = m(x, t, [c])
+                labels = [l for l, _, _ in eng.profile_ops()]
+                eng.profile_read(reset=True)
+                res[k] = (y, {}, labels)
+            finally:
+                eng.set_option("profile", 0); eng.set_option("glds_wide", 1); eng.set_option("sb", 1)
+    n_w = {k: sum(" f2w " in l for l in res[k][2]) for k in res}
+    print("launches on the wide tile:", n_w)
+    assert n_w["off"] == 0 and n_w["force"] > n_w["auto"] and (n_w["auto"] >= 10 if (n, hw) == (64, 64) else True), n_w
+    y0, a0, _ = res["off"]
+    for k in ("auto", "force"):
+        y, acts, _ = res[k]
+        for l in acts:
+            e = rel_rms(acts[l].float().cpu().numpy(), a0[l].float().cpu().numpy())
+            assert e < 3e-3, (k, l, e)
+        e = rel_rms(y.cpu().numpy(), y0.cpu().numpy())
+        print(f"wide tile {k}: network output vs the other tiles, rel-RMS {e:.2e}")
+        assert e < 6e-3, (k, e)
+    with torch.no_grad():
+        ref = om(x[:1].cpu(), t[:1], [c[:1].cpu()])
+    for k in res:
+        e = rel_rms(res[k][0][:1].cpu().numpy(), ref.numpy())
+        print(f"wide tile {k}: sample 0 vs oracle {e:.3e}")
+        assert e < 2e-2, (k, e)
 
 
 @pytest.mark.parametrize("n,hw,splitk", [(20, 72, 0), (7, 40, 0), (64, 64, 1), (3, 64, 1), (1, 64, 1)])

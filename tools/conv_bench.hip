@@ -3,13 +3,26 @@
 //   ./conv_bench.out N H W Cin Cout taps xform bn [ksplit]
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <algorithm>
 #include <array>
+#ifdef TD_BENCH_EXTERN   // kernels linked from separately compiled objects (tools/build_bench.sh: the conv_glds family takes minutes to compile, the flavour under work seconds)
+#include <algorithm>
+#include "conv_common.h"
+namespace td {
+hipError_t launch_conv(const ConvParams& p, int dtype, bool narrow, int bn, int ksplit_variant, hipStream_t st);
+hipError_t launch_conv_glds(const ConvParams& p, int dtype, bool narrow, int bn, int variant, hipStream_t st);
+hipError_t launch_conv_glds_wide(const ConvParams& p, int dtype, int bn, hipStream_t st);
+extern int g_bench_extra_lds;
+}
+#else
 #include "conv_igemm.hip"
 #include "conv_glds.hip"
+#include "conv_glds_wide.hip"
+#endif
 using namespace td;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 __global__ void __launch_bounds__(256) bench_prefetch_kernel(const uint4* __restrict__ w, size_t n16, uint4* sink) {
@@ -53,7 +66,7 @@ int main(int argc, char** argv) {
         p.nseg = 2; p.seg[1].src = x2; p.seg[1].C = Cin2; p.seg[1].cstride = Cin2; p.seg[1].Hs = H; p.seg[1].Ws = W; p.seg[1].taps = taps2; p.seg[1].xform = 0; p.seg[1].scale = 1.f;
     }
     p.dma1x1 = getenv("TD_DMA1X1") ? atoi(getenv("TD_DMA1X1")) : 1;
-    bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4) ? 4 : 2) : 1; int TH = flavor == 8 ? 4 : ((flavor == 2 || flavor == 4) && !narrow) ? 16 : 8;  // flavor 8 = conv_glds variant 2 (tiny tile)
+    bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4) ? 4 : 2) : 1; int TH = flavor == 8 ? 4 : ((flavor == 2 || flavor == 4 || flavor == 9) && !narrow) ? 16 : 8;  // flavor 8 = conv_glds variant 2 (tiny tile); 9 = conv_glds_wide.hip (256 px x bn, 4 waves, two workgroups per CU)
     p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH; p.img_groups = (N + NIMG - 1) / NIMG; p.n_ntiles = Cout / bn;
     p.epi = epi; p.out = out; p.out_cstride = Cout;
     { void* z; CK(hipMalloc(&z, 4096)); CK(hipMemset(z, 0, 4096)); p.zeros = z; }
@@ -68,7 +81,7 @@ int main(int argc, char** argv) {
     if (getenv("TD_EXTRA_LDS")) g_bench_extra_lds = atoi(getenv("TD_EXTRA_LDS"));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto L = [&](const ConvParams& q) { return flavor == 8 ? launch_conv_glds(q, 1, narrow, bn, 2, st) : flavor >= 2 ? launch_conv_glds(q, 1, narrow, bn, flavor - 2, st) : launch_conv(q, 1, narrow, bn, flavor, st); };
+    auto L = [&](const ConvParams& q) { return flavor == 9 ? launch_conv_glds_wide(q, 1, bn, st) : flavor == 8 ? launch_conv_glds(q, 1, narrow, bn, 2, st) : flavor >= 2 ? launch_conv_glds(q, 1, narrow, bn, flavor - 2, st) : launch_conv(q, 1, narrow, bn, flavor, st); };
     for (int i = 0; i < 4; ++i) CK(L((chain && (i & 1)) ? p2 : p));
     CK(hipStreamSynchronize(st));
     const int reps = 20;
@@ -108,6 +121,32 @@ int main(int argc, char** argv) {
         size_t bad = 0, nz = 0; for (size_t i = 0; i < o0.size(); ++i) { bad += o0[i] != o1[i]; nz += (o1[i] & 0x7fff) != 0; }
         printf("  check dma1x1 1 vs 0: %zu / %zu outputs differ, nonzero outputs %zu%s\n", bad, o0.size(), nz, ksplit > 1 ? "  (split-K: `out` is written by the reduce launch)" : "");
     }
+    if (flavor == 9 && !getenv("TD_NO_CMP")) {   // the wide tile against the 128-pixel tile of conv_glds: same K order, same MFMA -> out, second output and sum-of-squares planes bit for bit
+        const int bn0 = (Cout % bn == 0 && (bn == 96 || bn == 128 || bn == 64)) ? bn : 96;
+        std::vector<uint16_t> o[2], o2[2]; std::vector<float> ss[2];
+        for (int d = 0; d < 2; ++d) {
+            ConvParams q = p;
+            if (d == 0) { q.n_ntiles = Cout / bn0; q.tiles_y = (H + 7) / 8; }
+            CK(hipMemset(out, 0, M * Cout * 2)); if (p.out2) CK(hipMemset(p.out2, 0, M * Cout * 2)); if (p.out_sumsq) CK(hipMemset(p.out_sumsq, 0, M * (Cout / 32) * 4));
+            CK(d == 0 ? launch_conv_glds(q, 1, narrow, bn0, 1, st) : L(q)); CK(hipStreamSynchronize(st));
+            o[d].resize(M * Cout); CK(hipMemcpy(o[d].data(), out, M * Cout * 2, hipMemcpyDeviceToHost));
+            if (p.out2) { o2[d].resize(M * Cout); CK(hipMemcpy(o2[d].data(), p.out2, M * Cout * 2, hipMemcpyDeviceToHost)); }
+            if (p.out_sumsq) { ss[d].resize(M * (Cout / 32)); CK(hipMemcpy(ss[d].data(), p.out_sumsq, ss[d].size() * 4, hipMemcpyDeviceToHost)); }
+        }
+        // another K order (channel half outside the taps): fp32 sums rounded differently -> the bf16 outputs may differ in the last place; report how many do,
+        // by how many bf16 ulps at most, and the relative RMS difference (a wrong tap / channel / cout mapping shows as O(1))
+        auto bf = [](uint16_t h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; };
+        auto cmp16 = [&](const std::vector<uint16_t>& a, const std::vector<uint16_t>& b, const char* name) {
+            size_t bad = 0, nz = 0; int maxulp = 0; double num = 0, den = 0;
+            for (size_t i = 0; i < a.size(); ++i) { nz += (b[i] & 0x7fff) != 0; if (a[i] != b[i]) { ++bad; const int d = abs((int)(a[i] & 0x7fff) - (int)(b[i] & 0x7fff)); maxulp = std::max(maxulp, ((a[i] ^ b[i]) & 0x8000) ? 9999 : d); }
+                const double x = bf(a[i]), y = bf(b[i]); num += (x - y) * (x - y); den += x * x; }
+            printf("  check wide vs conv_glds bn%d small, %s: %zu / %zu differ (nonzero %zu), max %d bf16 ulp, rel-RMS %.3e\n", bn0, name, bad, a.size(), nz, maxulp, den > 0 ? sqrt(num / den) : 0.0);
+        };
+        cmp16(o[0], o[1], "out");
+        if (!o2[0].empty()) cmp16(o2[0], o2[1], "out2");
+        if (!ss[0].empty()) { double num = 0, den = 0; for (size_t i = 0; i < ss[0].size(); ++i) { num += ((double)ss[0][i] - ss[1][i]) * ((double)ss[0][i] - ss[1][i]); den += (double)ss[0][i] * ss[0][i]; }
+            printf("  check wide vs conv_glds, sumsq planes: rel-RMS %.3e\n", den > 0 ? sqrt(num / den) : 0.0); }
+    }
     if (getenv("TD_CMP_BN") && (flavor == 2 || flavor == 3)) {   // same K order, same MFMA: another cout tile width must give the same bits
         const int bn0 = atoi(getenv("TD_CMP_BN"));
         std::vector<uint16_t> o0(M * Cout), o1(M * Cout);
@@ -121,7 +160,7 @@ int main(int argc, char** argv) {
     }
 #ifdef TD_TRACE
     {
-        int wgs = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups; const int nw = flavor == 4 ? 12 : (flavor == 3 ? 4 : 8), TS = 16;
+        int wgs = p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups; const int nw = flavor == 4 ? 12 : ((flavor == 3 || flavor == 9) ? 4 : 8), TS = 16;
         std::vector<unsigned long long> tb((size_t)wgs * nw * TS);
         CK(hipMemcpy(tb.data(), partial, tb.size() * 8, hipMemcpyDeviceToHost));
         double s[5] = {0, 0, 0, 0, 0}; unsigned long long t0 = ~0ull, t1 = 0;
