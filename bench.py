@@ -33,7 +33,7 @@ WEIGHT_BYTES_BF16 = 253_688_037 * 2  # algorithmic minimum HBM bytes per forward
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-PROFILE_JSON = os.path.join(ROOT, "profiles", "r05_hbm_traffic_and_mfma_util.json")   # stamped with the library build id it was collected with
+PROFILE_JSON = os.path.join(ROOT, "profiles", "r06_hbm_traffic_and_mfma_util.json")   # stamped with the library build id it was collected with
 
 # terrain-diffusion-30m base model (configs/diffusion_base/30m/diffusion_192-3.cfg:54-68)
 BASE_CONFIG = dict(image_size=512, in_channels=5, out_channels=5, model_channels=192, model_channel_mults=[1, 2, 3, 4], layers_per_block=3,
@@ -214,10 +214,15 @@ def main():
                 "end_to_end_achieved": round(e2e_tflops, 2), "end_to_end_frac": round(e2e_tflops / peak, 4)}
         if not args.no_kernel_profile and world == 1:
             # kernel level: HIP events on the engine's own stream around every conv launch (eager mode, no graph), one extra step
+            # (one lane, whatever the timed region used: every kernel at the FULL batch, one after the other -- what `rocprofv3 --kernel-trace` of
+            # `bench.py --engine-opts dual_stream=0` sees; two lanes are accounted for below)
+            dual_on = "dual_stream=0" not in args.engine_opts   # engine default since round 6 (profiles/r06_dual_stream_ab.txt)
+            eng.set_option("dual_stream", 0)
             eng.set_option("profile", 1)
             eng.profile_read(reset=True); eng.profile_read_glds(reset=True)
             one_step(10_000)
             sync()
+            eng.set_option("dual_stream", 1 if dual_on else 0)
             g_ms, g_flop, g_n = eng.profile_read_glds(reset=True)
             ops_ = eng.profile_ops()
             sb_rows = [(float(re.search(r" gf([0-9.]+)", l_).group(1)), ms_, n_) for l_, ms_, n_ in ops_ if re.search(r" f[45]\w* bn", l_)]
@@ -234,7 +239,6 @@ def main():
                                               "achieved": round(sb_gf / sb_ms, 2) if sb_ms > 0 else None, "unit": "TFLOP/s"}
             if g_n > 0:   # dominant kernel family: the LDS-DMA implicit-GEMM conv (terrain_diffusion_amd/csrc/conv_glds.hip)
                 ach = g_flop / (g_ms * 1e-3) / 1e12
-                dual_on = "dual_stream=0" not in args.engine_opts   # engine default since round 6 (profiles/r06_dual_stream_ab.txt)
                 lanes = 2 if (dual_on and min(tiles_per_step, 64) >= 32) else 1
                 share = g_ms / (conv_ms + other_ms)
                 iso = {"achieved": round(ach, 2), "frac": round(ach / peak, 4), "avg_launch_us": round(g_ms / g_n * 1e3, 3), "kernel_ms_per_step": round(g_ms, 3)}
@@ -252,12 +256,14 @@ def main():
                     act_ms = ms_per_step * share
                     eff = g_flop / (act_ms * 1e-3) / 1e12
                     roof.update({"achieved": round(eff, 2), "frac": round(eff / peak, 4), "avg_launch_us": round(act_ms / g_n * 1e3, 3), "kernel_ms_per_step": round(act_ms, 3),
-                                 "lanes_serialised": iso,
+                                 "single_lane": iso,
                                  "lanes_note": "batches of >= 32 windows run as two concurrent half-batch lanes on two HIP streams (independent tiles: the other lane's kernels fill "
-                                               "the CUs that a kernel's last partial round, launch gap and epilogue tail leave idle). achieved / avg_launch_us = the kernel family's "
-                                               "throughput over the wall time it occupies in the TIMED region (step time x its share of kernel time). lanes_serialised = the same "
-                                               "launches timed one by one with HIP events on one stream (profile pass; kernels at the lane batch size, no overlap). Under rocprofv3 "
-                                               "the two lanes' kernels overlap pairwise: traced durations are up to 2x avg_launch_us and their sum exceeds the wall time."})
+                                               "the CUs that a kernel's last partial round, launch gap and epilogue tail leave idle). achieved / frac / avg_launch_us = the kernel family's "
+                                               "algorithmic FLOP over the wall time it occupies in the TIMED region (step time x its share of U-Net kernel time; avg_launch_us = that time / "
+                                               "the launches of a one-lane step). single_lane = the family's launches at the full batch of 64 timed one by one with HIP events on the engine's "
+                                               "stream (extra step, option dual_stream = 0): the figure that `rocprofv3 --kernel-trace` of `bench.py --engine-opts dual_stream=0` reproduces "
+                                               "(profiles/r06_bench_grid8_kernel_trace_summary.csv). Traced under rocprofv3 with two lanes, kernels overlap pairwise and their durations "
+                                               "sum to more than the wall time."})
             else:
                 roof.update({"achieved": roof["end_to_end_achieved"], "frac": roof["end_to_end_frac"]})
             if workload in ("grid8", "tiles") and tiles_per_step == 64 and args.dtype == "bf16":
@@ -302,7 +308,7 @@ def main():
                                               "kernel": "td::conv_sb_kernel (small-batch flavour: K split over the waves of a workgroup) at the 64x64 / 32x32 levels, td::conv_s16_kernel "
                                                         "(64 px x 16 couts, no split-K over workgroups) at the 16x16 level, conv_sb + td::conv_splitk_reduce_kernel at the 8x8 level",
                                               "note": f"algorithmic bytes = {E} forwards x {WEIGHT_BYTES_BF16} B of bf16 weights (activations of one tile are negligible); "
-                                                      "measured HBM bytes per forward: profiles/r05_batch_sweep.txt"}
+                                                      "measured HBM bytes per forward: profiles/r06_batch1_hbm_traffic.json"}
 
         if world == 1 and not args.no_latency and workload == "grid8" and args.dtype == "bf16":
             # N = 1 point of the STRONG-scaling workload the driver runs at N > 1 (grid32, BASELINE configs[3]): one full step, timed live in this

@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
         else if ((S) == 17 && r_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS + NBI) : "memory");    \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
         if ((S) == 6 || (S) == 15) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* this wave's patch writes of the previous half-step are out */ \
+        TDW_T(tM_); TDW_TACC(tr_stage, tA_, tM_);   /* (trace builds: the share of the wait that is this wave's own DMA pieces landing; the rest is the barrier) */ \
         __builtin_amdgcn_s_barrier();                                                                        \
         asm volatile("" ::: "memory");                                                                       \
         TDW_T(tB_); TDW_TACC(tr_wait, tA_, tB_);                                                             \

@@ -822,7 +822,8 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                 // Wide tile (conv_glds_wide.hip, round 6): 256 px x 96 / 64 couts on 4 waves, two workgroups per CU, 32-channel K-groups with a double-buffered
                 // patch -- half the weight bytes per MFMA through the CU's L2 -> LDS path, 0.6x the LDS fragment reads, half as many workgroup
                 // prologues / epilogue drains, no restage barrier.  Taken where its grid still gives every CU slot >= "glds_wide_min_wgs" / 512 workgroups
-                // (the 64x64 and 32x32 levels of a 64-window batch, the decoder's 512x512 / 256x256 levels) for launches it serves at full speed: pure
+                // (the 64x64, 32x32 and 16x16 levels of a 64-window batch -- 384 workgroups of 256 pixels there are one round on 3/4 of the slots where 768 of 128 pixels
+                // are one and a half rounds: +0.9 % on the bench line, tools/r06_exp3.sh --, the decoder's 512x512 / 256x256 levels) for launches it serves at full speed: pure
                 // 3x3 K (its 1x1 tail is not pipelined), 16-bit output in 16-byte runs.  Another K order than the other tiles (channel half outside the
                 // taps): never in batch_invariant mode, where the choice must not depend on the batch.  Option "glds_wide": 0 never, 1 this rule, 2 wherever legal.
                 {
@@ -832,7 +833,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                     const int bnw = cw.cout_pad % 96 == 0 ? 96 : (cw.cout_pad % 64 == 0 ? 64 : 0);
                     const int64_t wgs_w = bnw ? tiles(16, 1) * (cw.cout_pad / bnw) : 0;
                     if (wmode != 0 && !inv && fv < 0 && fbn == 0 && !op.narrow && p.ksplit == 1 && bnw && !out_f32 && (cw.cout & 7) == 0 && p.nseg <= 3 && (pure3 || wmode == 2) &&
-                        (wmode == 2 || wgs_w >= u->eng->option("glds_wide_min_wgs", 1024))) {
+                        (wmode == 2 || wgs_w >= u->eng->option("glds_wide_min_wgs", 384))) {
                         op.glds_variant = 3; op.bn = bnw;
                         p.tiles_x = (w + 15) / 16; p.tiles_y = (h + 15) / 16; p.img_groups = N; p.n_ntiles = cw.cout_pad / bnw;
                     }

@@ -4,9 +4,11 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_new; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-latency"
+# ONE sampler lane (--engine-opts dual_stream=0): per-kernel durations and per-dispatch counters are only meaningful when kernels do not overlap; the
+# engine's default (two half-batch lanes, round 6) is what the bench LINE times, its `roofline.single_lane` leg is what these files reproduce
+BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-latency --engine-opts dual_stream=0"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
-for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
+for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
   tag=$(echo $c | cut -d' ' -f1)
   timeout 900 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$tag -- $BENCH > $OUT/pmc_$tag.log 2>&1
 done
@@ -44,6 +46,10 @@ for k, cs in cnt.items():
     if g("FETCH_SIZE") is not None: e["hbm_read_bytes_per_launch"] = round(g("FETCH_SIZE") * 1024 * 2)   # KB; doubled: gfx950 correction (guide)
     if g("WRITE_SIZE") is not None: e["hbm_write_bytes_per_launch"] = round(g("WRITE_SIZE") * 1024)
     if g("SQ_VALU_MFMA_BUSY_CYCLES") and g("GRBM_GUI_ACTIVE"): e["mfma_util"] = round(g("SQ_VALU_MFMA_BUSY_CYCLES") / (g("GRBM_GUI_ACTIVE") / 8 * 1024), 4)  # busy cycles / (cycles per XCD x 256 CUs x 4 SIMDs)
+    if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and (g("TCC_HIT_sum") + g("TCC_MISS_sum")) > 0:
+        e["l2_hit_rate"] = round(g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")), 4)
+        e["l2_requests_per_launch"] = round(g("TCC_HIT_sum") + g("TCC_MISS_sum"))
+    if g("TCC_EA0_RDREQ_sum") is not None: e["fabric_read_requests_per_launch"] = round(g("TCC_EA0_RDREQ_sum")); e["fabric_read_requests_32B_per_launch"] = round(g("TCC_EA0_RDREQ_32B_sum") or 0)
     if g("SQ_LDS_IDX_ACTIVE"): e["lds_bank_conflict_share"] = round((g("SQ_LDS_BANK_CONFLICT") or 0.0) / g("SQ_LDS_IDX_ACTIVE"), 4)
     if g("SQ_WAVE_CYCLES"): e.update({"wait_any_share": round(g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 4), "wait_inst_share": round(g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"), 4), "active_inst_share": round(g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES"), 4)})
     if g("SQ_INSTS_VALU") and g("SQ_INSTS_VALU_MFMA_MOPS_BF16"):
@@ -55,7 +61,7 @@ sys.path.insert(0, R)
 import __graft_entry__ as ge
 import ctypes as C
 _l = C.CDLL(ge.LIB); _l.td_build_id.restype = C.c_char_p
-json.dump({"csrc_sha16": ge.csrc_sha16(), "library_build_id": _l.td_build_id().decode(), "note": "rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-latency` (batch 64 x 20 solver steps per bench step). FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced stream); WRITE_SIZE uncalibrated; units KB -> bytes x1024. mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs).", "kernels": kern}, open(out + "/hbm_traffic_and_mfma_util.json", "w"), indent=1)
+json.dump({"csrc_sha16": ge.csrc_sha16(), "library_build_id": _l.td_build_id().decode(), "seam_sha16": ge.seam_sha16(), "note": "rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-latency --engine-opts dual_stream=0` (batch 64 x 20 solver steps per bench step, ONE sampler lane so that dispatches do not overlap). FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced stream); WRITE_SIZE uncalibrated; units KB -> bytes x1024. mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs).", "kernels": kern}, open(out + "/hbm_traffic_and_mfma_util.json", "w"), indent=1)
 # batch-1 leg: HBM bytes per forward (3 bench steps x 20 forwards of ONE tile), all kernels of the U-Net
 b1 = collections.defaultdict(float)
 for f in glob.glob(out + "/b1pmc_*/**/*counter_collection.csv", recursive=True):
