@@ -51,15 +51,24 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
     constexpr int WM = 64, MT = 2, NT = BN / 32;
     constexpr int CHUNK = 64, HALF = 32, PER16 = 8;
     constexpr int A_ITERS = (NPATCH * 4 + NTHR - 1) / NTHR;               // 6 (four 16-byte pieces per patch pixel and channel half)
-    constexpr int NBI = (BN * 64 + NTHR * 16 - 1) / (NTHR * 16);          // LDS-DMA pieces per thread and half K-step (BN 96: 2 -- rows 96 .. 127 of the second belong to the next cout tile, never read)
-    constexpr int H_BYTES = NBI * NTHR * 16, RING = 3;
+    // Weight ring: FOUR slots of exactly BN x 64 bytes, half tiles requested THREE half-steps before their taps (two before the barrier that publishes
+    // them).  First build: three slots, one half-step of lead -- the s_memtime split of the tap-entry wait said 60 % of it (9 - 17 % of a workgroup's
+    // life) was the wave's own LDS-DMA pieces still in flight, the rest barrier skew (profiles/r06_wide_tile_phase_traces.txt).
+    // A half tile is BN x 4 sixteen-byte pieces: 256 / 384 / 512 for BN 64 / 96 / 128.  At BN 96 the second piece of waves 2 and 3 has no rows left;
+    // they issue it all the same -- into a 2 KB dump area, from the address of their first piece (an L1 hit) -- so that every wave counts the same
+    // number of pieces per half tile (the s_waitcnt immediates are compile-time).
+    constexpr int NBI = (BN * 64 + NTHR * 16 - 1) / (NTHR * 16);
+    constexpr int H_BYTES = BN * 64, RING = 4;
+    constexpr bool HAS_DUMP = (BN * 64) % (NTHR * 16) != 0;
+    constexpr int DUMP_BASE = RING * H_BYTES;
     constexpr int PITCH = 80;
-    constexpr int A_BASE = RING * H_BYTES, A_BYTES = NPATCH * PITCH;      // two patch buffers: A_BASE, A_BASE + A_BYTES
+    constexpr int A_BASE = DUMP_BASE + (HAS_DUMP ? 2048 : 0), A_BYTES = NPATCH * PITCH;      // two patch buffers: A_BASE, A_BASE + A_BYTES
     constexpr int RN_BASE = A_BASE + 2 * A_BYTES;
     constexpr int CV_BASE = RN_BASE + (NPATCH * 4 + 15) / 16 * 16;
     constexpr int NU = NT * 2;
     static_assert(BN % 32 == 0 && BN <= NTHR, "tile shape");
-    static_assert((RING - 1) * H_BYTES + (NT - 1) * 2048 + 64 < 65536 && A_BYTES + 2 * PW * PITCH + 2 * PITCH + 64 < 65536, "ds_read offset field");
+    static_assert((NT - 1) * 2048 + 64 < 65536 && A_BYTES + 2 * PW * PITCH + 2 * PITCH + 64 < 65536, "ds_read offset field");
+    static_assert(!HAS_DUMP || NBI == 2, "dump piece");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // the ONLY LDS object: its offset is 0
     float* s_rn = (float*)(smem + RN_BASE);
@@ -109,21 +118,27 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
         const int pos = tid + i * NTHR, r = pos >> 2, j = (pos & 3) ^ ((r >> 2) & 3), x = TD_SWZ(r);
         wvoff[i] = (unsigned)(r * 128 + ((((x & 4) | (j ^ (x & 3)))) << 4));
     }
+    // LDS destination of piece i of a half tile in the slot at byte offset SLOT (wave-uniform): wave * 1 KB + i * 4 KB inside the slot; the rowless
+    // second piece of waves 2 / 3 at BN 96 goes to the dump area.  wslot = slot of the next half tile to REQUEST, rslot = slot of the next to READ.
     const unsigned ldsw = (unsigned)wave * 1024u;
-    // half tile T (0 .. 19; 18 / 19 = taps 0 / 1 of the NEXT unit) of the unit at wchunk into ring slot T % 3
+    const bool dump1 = HAS_DUMP && wave >= 2;
+    const unsigned voff1 = NBI > 1 ? (dump1 ? wvoff[0] : wvoff[NBI - 1]) : 0u;
+    unsigned wslot = 0, rslot = 0;
+#define TDW_SLOT_NEXT(X) { X += H_BYTES; if (X == RING * H_BYTES) X = 0; }
+    // half tile T (0 .. 20; 18 .. 20 = taps 0 .. 2 of the NEXT unit) of the unit at wchunk
 #define TDW_DMA(TILE)                                                                                        \
     {                                                                                                        \
         if ((TILE) == 9) wnext = wchunk;                                                                     \
         if ((TILE) == 18) { wnext += wstep; wchunk = wnext; }                                                \
-        if ((TILE) >= 9 && (TILE) < 18) {                                                                    \
-            _Pragma("unroll") for (int i_ = 0; i_ < NBI; ++i_) { const unsigned v_ = wvoff[i_] ^ 64u; TD_GLDS16(v_, wnext, ldsw, ((TILE) % RING) * H_BYTES + i_ * NTHR * 16); } \
-        } else {                                                                                             \
-            _Pragma("unroll") for (int i_ = 0; i_ < NBI; ++i_) TD_GLDS16(wvoff[i_], wnext, ldsw, ((TILE) % RING) * H_BYTES + i_ * NTHR * 16); \
-        }                                                                                                    \
+        const unsigned x_ = ((TILE) >= 9 && (TILE) < 18) ? 64u : 0u;                                         \
+        { const unsigned v_ = wvoff[0] ^ x_; const unsigned m_ = ldsw + wslot; TD_GLDS16(v_, wnext, m_, 0); } \
+        if constexpr (NBI > 1) { const unsigned v_ = voff1 ^ x_; const unsigned m_ = dump1 ? (unsigned)DUMP_BASE + ldsw - 2048u : ldsw + wslot + 4096u; TD_GLDS16(v_, wnext, m_, 0); } \
+        TDW_SLOT_NEXT(wslot)                                                                                 \
         if ((TILE) != 8 && (TILE) != 17) wnext += wstep;                                                     \
     }
     TDW_DMA(0);
     TDW_DMA(1);
+    TDW_DMA(2);
     const bool cv_stage = k_epi == EPI_EMB_SILU && tid < BN;
     float cv_val = 0.f;
     if (cv_stage) {
@@ -153,12 +168,19 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
             if (ok_ && (seg_taps == 9 || in_)) aoff[it_] = src_pixel(n0, y_, x_, Hs_, Ws_, rs_) * cs_ + (tid & 3) * PER16; \
         }                                                                                                             \
     }
-    // (always issued -- offset 0 for zero-fill pieces -- so that the vmcnt bookkeeping of the loop is exact)
+    // Always issued (offset 0 for zero-fill pieces) so that the vmcnt bookkeeping of the loop is exact -- and issued by INLINE ASM: hipcc's wait-count pass
+    // does not see these loads, so it never guards their registers with waits of its own (with two half tiles always in flight, its `vmcnt(5 ... 0)` in
+    // front of the LDS writes would drain the weight stream); the loop's counted waits cover them, and TDW_PIN_A -- placed behind such a wait -- is the
+    // point from which the compiler may use the values.
 #define TDW_LOAD_A(CH, HF)                                                                             \
     {                                                                                                  \
         const T* src_ = seg_src + (CH) * CHUNK + (HF) * HALF;                                          \
-        _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) av[it_] = *(const u32x4*)(src_ + (aoff[it_] >= 0 ? aoff[it_] : 0)); \
+        _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) {                                    \
+            const unsigned o_ = (unsigned)(aoff[it_] >= 0 ? aoff[it_] : 0) * (unsigned)sizeof(T);      \
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(av[it_]) : "v"(o_), "s"(src_) : "memory"); \
+        }                                                                                              \
     }
+#define TDW_PIN_A() { _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) asm volatile("" : "+v"(av[it_])); }
 #define TDW_STORE_A(BUF)                                                                               \
     {                                                                                                  \
         _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) {                                    \
@@ -233,6 +255,8 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) wbase[ks] = (unsigned)(l31 * 64 + (((ks * 2 + lh) ^ ((l31 >> 2) & 3)) << 4));
     __syncthreads();  // s_rn visible
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the first patch (and the three half tiles requested in front of it)
+    TDW_PIN_A()
     TDW_STORE_A(0);
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -248,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
     // fragments of k-step KS (0 / 1) of the half K-step in ring slot SLOT, patch buffer BUF, tap offset TOFF
 #define TDW_FRAG_READ(WF, XF, SLOT, KS, BUF, TOFF)                                                           \
     {                                                                                                        \
-        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) WF[j_] = *(const u32x4*)(smem + wbase[KS] + ((SLOT) * H_BYTES + j_ * 2048)); \
+        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) WF[j_] = *(const u32x4*)(smem + (wbase[KS] + (SLOT)) + j_ * 2048);   /* SLOT: wave-uniform byte offset of the ring slot */ \
         _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_) XF[i_] = *(const u32x4*)(smem + xbase[i_] + ((BUF) * A_BYTES + (TOFF) + (KS) * 32)); \
     }
 #define TDW_FRAG_MFMA(WF, XF)                                                                                \
@@ -270,28 +294,26 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
 #define TDW_HS(S)                                                                                            \
     {                                                                                                        \
         TDW_T(tA_);                                                                                          \
-        if ((S) == 1 || ((S) == 10 && nxt)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS) : "memory");   \
-        else if ((S) == 16 && r_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS) : "memory");          \
-        else if ((S) == 17 && r_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS + NBI) : "memory");    \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+        /* in flight, oldest first: half tile S + 1 (needed now), [patch loads of S - 2], half tile S + 2, [patch loads of S - 1] */ \
+        if ((S) == 1 || (S) == 2 || (((S) == 10 || (S) == 11) && nxt)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS + NBI) : "memory"); \
+        else if ((S) >= 16 && !nxt) { if (r_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI) : "memory");                                      \
         if ((S) == 6 || (S) == 15) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* this wave's patch writes of the previous half-step are out */ \
         TDW_T(tM_); TDW_TACC(tr_stage, tA_, tM_);   /* (trace builds: the share of the wait that is this wave's own DMA pieces landing; the rest is the barrier) */ \
         __builtin_amdgcn_s_barrier();                                                                        \
         asm volatile("" ::: "memory");                                                                       \
         TDW_T(tB_); TDW_TACC(tr_wait, tA_, tB_);                                                             \
-        if ((S) == 2 || ((S) == 11 && nxt)) {                                                                \
-            _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) asm volatile("" : "+v"(av[it_]));      \
-        }                                                                                                    \
-        TDW_DMA((S) + 2);                                                                                    \
+        if ((S) == 3 || ((S) == 12 && nxt)) TDW_PIN_A()   /* (the wait above completed the patch loads) */ \
+        if ((S) + 3 < 18 || nxt) TDW_DMA((S) + 3);   /* (nothing is requested past the end of the launch's 3x3 part) */ \
         if ((S) == 0) TDW_LOAD_A(chunk, 1);                                                                  \
         if ((S) == 9 && nxt) { if (newseg) TDW_SEG_BEGIN(seg + 1); TDW_LOAD_A(newseg ? 0 : chunk + 1, 0); }  \
         if ((S) == 15 && r_now) TDW_LOAD_R()                                                                 \
         if ((S) == 5) TDW_STORE_A(1);                                                                        \
         if ((S) == 14 && nxt) TDW_STORE_A(0);                                                                \
         TDW_FRAG_MFMA(wfA_, xfA_);                                                                           \
-        if ((S) < 17 || nxt) TDW_FRAG_READ(wfA_, xfA_, ((S) + 1) % RING, 0, (((S) + 1) / 9) & 1, TDW_TOFF(((S) + 1) % 9)); \
+        if ((S) < 17 || nxt) TDW_FRAG_READ(wfA_, xfA_, rslot, 0, (((S) + 1) / 9) & 1, TDW_TOFF(((S) + 1) % 9)); \
         TDW_FRAG_MFMA(wfB_, xfB_);                                                                           \
-        if ((S) < 17 || nxt) TDW_FRAG_READ(wfB_, xfB_, ((S) + 1) % RING, 1, (((S) + 1) / 9) & 1, TDW_TOFF(((S) + 1) % 9)); \
+        if ((S) < 17 || nxt) { TDW_FRAG_READ(wfB_, xfB_, rslot, 1, (((S) + 1) / 9) & 1, TDW_TOFF(((S) + 1) % 9)); TDW_SLOT_NEXT(rslot) } \
         __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
         __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);                                             \
         __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                             \
@@ -300,12 +322,13 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
     int seg = 0, chunk = 0;
     if (n3 > 0) {
         // entry of the pipeline: this wave's patch writes are out, half tiles 0 and 1 were issued a prologue ago
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NBI) : "memory");   // half tile 0 (1 and 2 stay in flight)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        TDW_FRAG_READ(wfA_, xfA_, 0, 0, 0, TDW_TOFF(0));
-        TDW_FRAG_READ(wfB_, xfB_, 0, 1, 0, TDW_TOFF(0));
+        TDW_FRAG_READ(wfA_, xfA_, rslot, 0, 0, TDW_TOFF(0));
+        TDW_FRAG_READ(wfB_, xfB_, rslot, 1, 0, TDW_TOFF(0));
+        TDW_SLOT_NEXT(rslot)
         for (int u = 0; u < n3; ++u) {
             const bool nxt = u + 1 < n3;
             const bool newseg = nxt && chunk + 1 == seg_nchunks;
@@ -333,16 +356,18 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
                     TDW_LOAD_A(ch, hf);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();   // every wave is done with patch buffer 0 and ring slot 0
-                    asm volatile("" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    TDW_PIN_A()
                     TDW_STORE_A(0);
-#pragma unroll
-                    for (int i_ = 0; i_ < NBI; ++i_) { const unsigned v_ = hf ? (wvoff[i_] ^ 64u) : wvoff[i_]; TD_GLDS16(v_, w1, ldsw, i_ * NTHR * 16); }
+                    { const unsigned x_ = hf ? 64u : 0u;
+                      { const unsigned v_ = wvoff[0] ^ x_; TD_GLDS16(v_, w1, ldsw, 0); }
+                      if constexpr (NBI > 1) { const unsigned v_ = voff1 ^ x_; const unsigned m_ = dump1 ? (unsigned)DUMP_BASE + ldsw - 2048u : ldsw + 4096u; TD_GLDS16(v_, w1, m_, 0); } }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
-                    TDW_FRAG_READ(wfA_, xfA_, 0, 0, 0, TDW_TOFF(4));
-                    TDW_FRAG_READ(wfB_, xfB_, 0, 1, 0, TDW_TOFF(4));
+                    TDW_FRAG_READ(wfA_, xfA_, 0u, 0, 0, TDW_TOFF(4));
+                    TDW_FRAG_READ(wfB_, xfB_, 0u, 1, 0, TDW_TOFF(4));
                     TDW_FRAG_MFMA(wfA_, xfA_);
                     TDW_FRAG_MFMA(wfB_, xfB_);
                 }
@@ -356,9 +381,11 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
 #undef TDW_FRAG_READ
 #undef TDW_FRAG_MFMA
 #undef TDW_LOAD_A
+#undef TDW_PIN_A
 #undef TDW_STORE_A
 #undef TDW_SEG_BEGIN
 #undef TDW_DMA
+#undef TDW_SLOT_NEXT
 
     TDW_T(tr_loop);
     // ---------------- epilogue (conv_glds.hip's wide / narrow paths; no split-K here)
@@ -459,8 +486,9 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
 template <typename T, int BN>
 static hipError_t launch_glds_wide_cfg(const ConvParams& p, hipStream_t st) {
     constexpr int NPATCH = 18 * 18;
-    constexpr size_t RING_BYTES = 3 * (size_t)(((BN * 64 + 4095) / 4096) * 4096);
+    constexpr size_t RING_BYTES = 4 * (size_t)(BN * 64) + ((BN * 64) % 4096 ? 2048 : 0);   // four exact slots (+ the dump area of the rowless pieces, BN 96)
     constexpr size_t LDS = RING_BYTES + 2 * (size_t)NPATCH * 80 + (NPATCH * 4 + 15) / 16 * 16 + (size_t)BN * 4;
+    static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
     if (p.ksplit != 1 || p.W < 16 || p.CoutPad % BN || p.nseg < 1 || p.nseg > 3) return hipErrorInvalidValue;
     if (p.out_f32 || (p.Cout & 7) || p.epi == EPI_DPM_STEP) return hipErrorInvalidValue;   // the 16-byte-run epilogue only
     bool seen1 = false;   // 3x3 segments first
@@ -483,19 +511,17 @@ static hipError_t launch_glds_wide_cfg(const ConvParams& p, hipStream_t st) {
     return hipGetLastError();
 }
 
-// dtype: 1 bf16, 2 fp16; bn: 64 / 96 / 128.  16-wide maps only, tiles_y = ceil(H / 16), tiles_x = ceil(W / 16), img_groups = N, no split-K.
+// dtype: 1 bf16, 2 fp16; bn: 64 / 96 (a 128-cout tile needs 86 KB of LDS and 256+ registers: one workgroup per CU, which is what this flavour exists to avoid).  16-wide maps only, tiles_y = ceil(H / 16), tiles_x = ceil(W / 16), img_groups = N, no split-K.
 hipError_t launch_conv_glds_wide(const ConvParams& p, int dtype, int bn, hipStream_t st) {
 #ifdef TDW_ONLY96   // (development builds: one instantiation)
     return dtype == 1 && bn == 96 ? launch_glds_wide_cfg<__bf16, 96>(p, st) : hipErrorInvalidValue;
 #endif
     if (dtype == 2) {
         if (bn == 96) return launch_glds_wide_cfg<_Float16, 96>(p, st);
-        if (bn == 128) return launch_glds_wide_cfg<_Float16, 128>(p, st);
         if (bn == 64) return launch_glds_wide_cfg<_Float16, 64>(p, st);
         return hipErrorInvalidValue;
     }
     if (bn == 96) return launch_glds_wide_cfg<__bf16, 96>(p, st);
-    if (bn == 128) return launch_glds_wide_cfg<__bf16, 128>(p, st);
     if (bn == 64) return launch_glds_wide_cfg<__bf16, 64>(p, st);
     return hipErrorInvalidValue;
 }
