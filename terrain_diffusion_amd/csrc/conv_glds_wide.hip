@@ -445,8 +445,16 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
                         const f32x4 vb = {acc[i][j][8 * m + 4], acc[i][j][8 * m + 5], acc[i][j][8 * m + 6], acc[i][j][8 * m + 7]};
                         u32x4 o, o2;
                         epi_unit8<T>(e_epi, has_res, e_clip, want_ss, want_o2, va, vb, ca, cb, rw, rs, k_o2, o, o2, ssj[j]);
+#if defined(TDW_EPI_EXP) && TDW_EPI_EXP == 1      /* experiment (tools/conv_bench.hip only): no stores at all */
+                        if (o[0] == 0x12345678u && o2[1] == 0x9abcdef0u) *(u32x4*)(orow + j * 32 + m * 16) = o;
+#elif defined(TDW_EPI_EXP) && TDW_EPI_EXP == 2    /* experiment: the same bytes to WRONG, wave-linear addresses -- every store instruction covers 1 KB of whole lines */
+                        { T* lin_ = (T*)p.out + (((size_t)blockIdx.x * 4 + wave) * (MT * NU) + (i * NU + u)) * 512 + lane * 8;
+                          *(u32x4*)lin_ = o;
+                          if (want_o2) *(u32x4*)((T*)p.out2 + (lin_ - (T*)p.out)) = o2; }
+#else
                         *(u32x4*)(orow + j * 32 + m * 16) = o;
                         if (want_o2) *(u32x4*)((T*)p.out2 + (orow - (T*)p.out) + j * 32 + m * 16) = o2;
+#endif
                     }
                 };
                 if (e_epi == EPI_EMB_SILU) body(std::integral_constant<int, 1>{});

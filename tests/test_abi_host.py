@@ -162,10 +162,16 @@ def test_stamped_bench_line_belongs_to_its_sources(rnd):
     assert "configs[2]" in d["config"]["workload"] and d["dtype"] == "bf16" and d["vs_baseline"] is None and d["n_gpus"] == 1
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["peak"] == 2500.0 and r["bound"] == "mfma"
     assert abs(r["achieved"] - r["flop_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12) / r["achieved"] < 0.01
-    # the kernel trace of the same command: call-weighted average launch time of the conv_glds instantiations within 3 % of the live one
+    # the kernel trace: call-weighted average launch time of the conv_glds instantiations (the wide tile's kernel name contains the family's) within 3 % of
+    # the live one.  Round 6: the bench line runs two sampler lanes whose kernels overlap; the trace is taken on ONE lane (`--engine-opts dual_stream=0`)
+    # and reproduces the line's `roofline.single_lane` leg (same launches at the full batch, timed one by one with HIP events)
+    live = r["single_lane"] if r.get("lanes", 1) == 2 else r
+    if r.get("lanes", 1) == 2:
+        assert abs(live["frac"] - live["achieved"] / r["peak"]) < 1e-3
+        assert abs(live["achieved"] - r["flop_per_launch"] / (live["avg_launch_us"] * 1e-6) / 1e12) / live["achieved"] < 0.01
     rows = [x for x in csv.DictReader(open(os.path.join(root, "profiles", f"{rnd}_bench_grid8_kernel_trace_summary.csv"))) if r["kernel"].split("::")[-1].split(" ")[0] in x["kernel"]]
     calls, total = sum(int(x["calls"]) for x in rows), sum(float(x["total_us"]) for x in rows)
-    assert calls % r["launches_per_step"] == 0 and abs(total / calls - r["avg_launch_us"]) / r["avg_launch_us"] < 0.03
+    assert calls % r["launches_per_step"] == 0 and abs(total / calls - live["avg_launch_us"]) / live["avg_launch_us"] < 0.03
     # traffic: measured bytes per launch over the algorithmic bytes, with and without the pre-activated second output
     assert r["traffic_algorithmic_strict"] < r["traffic_algorithmic"] < r["traffic"]
     assert abs(r["traffic_over_algorithmic"] - r["traffic"] / r["traffic_algorithmic"]) < 2e-3
