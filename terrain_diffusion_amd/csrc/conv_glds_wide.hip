@@ -43,7 +43,10 @@ namespace td {
 #define TDW_TACC(acc, a, b)
 #endif
 
-template <typename T, int BN>
+// TAIL: the instantiation for launches whose K ends in 1x1 segments.  Its own code object because the tail's registers (stage addresses, cursor) would
+// otherwise push the pure-3x3 launches -- the majority -- over 256 VGPRs: hipcc then spills the LDS-DMA offset registers and reloads them from scratch inside
+// the half-step loop behind a vmcnt(0), which drains the weight stream.  The TAIL instantiation pays for its tail by not prefetching the residual runs.
+template <typename T, int BN, bool TAIL>
 __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams p) {
     typedef typename Half<T>::x8 hx8;
     constexpr int NTHR = 256, TH = 16, TW = 16, TPIX = 256;
@@ -181,24 +184,27 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
         }                                                                                              \
     }
 #define TDW_PIN_A() { _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) asm volatile("" : "+v"(av[it_])); }
+    // (ONE address register for the six pieces: piece it_ of thread tid is patch pixel (tid >> 2) + 64 it_, 16-byte slot tid & 3 -- written out so, because left
+    // to itself hipcc kept six piece addresses live across the K loop, spilled two of them, and reloaded them from scratch inside the loop behind a vmcnt(0))
+    const unsigned st_base = (unsigned)A_BASE + (unsigned)(tid >> 2) * PITCH + (unsigned)((tid & 3) << 4);
+    static_assert(4 * 64 + 63 < NPATCH && A_ITERS == 6, "pieces 0 .. 4 always lie inside the patch; piece 5 for tid < 16");
 #define TDW_STORE_A(BUF)                                                                               \
     {                                                                                                  \
         _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) {                                    \
-            const int e_ = tid + it_ * NTHR, pp_ = e_ >> 2, slot_ = e_ & 3;                            \
-            if (pp_ < NPATCH) {                                                                        \
+            if (it_ < 5 || tid < (NPATCH - 5 * 64) * 4) {                                              \
                 u32x4 v_ = aoff[it_] >= 0 ? av[it_] : u32x4{0u, 0u, 0u, 0u};                           \
                 if (TDW_XFORM_ON && seg_xform != 0 && aoff[it_] >= 0) {                                \
                     float s_ = seg_scale;                                                              \
-                    if (seg_xform == 2) s_ *= s_rn[pp_];                                               \
+                    if (seg_xform == 2) s_ *= s_rn[(tid >> 2) + it_ * 64];                             \
                     v_ = xform_piece<T>(v_, s_);                                                       \
                 }                                                                                      \
-                *(u32x4*)(smem + A_BASE + (BUF) * A_BYTES + pp_ * PITCH + (slot_ << 4)) = v_;          \
+                *(u32x4*)(smem + st_base + ((BUF) * A_BYTES + it_ * 64 * PITCH)) = v_;                 \
             }                                                                                          \
         }                                                                                              \
     }
     // residual runs of the wide epilogue: the first A_ITERS of the MT * NU units are requested during the LAST 3x3 unit into `av` (dead there), the rest
     // at the top of the epilogue (conv_glds.hip round 5)
-    const bool r_want = k_epi == EPI_RESIDUAL && k_hres;
+    const bool r_want = !TAIL && k_epi == EPI_RESIDUAL && k_hres;
     bool r_pref = false;
     const T* r_ptr[MT];
 #define TDW_R_ADDR()                                                                                                  \
@@ -242,14 +248,12 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
     if (cv_stage) s_cv[tid] = cv_val;
 
     // ---- MFMA operand addressing: weights = A operand (rows = couts), activations = B operand (cols = pixels)
-    int base_pp[MT];
     unsigned xbase[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         int img, ty, tx;
         frag_pixel<TW, TPIX>(wm * WM + i * 32, l31, img, ty, tx);
-        base_pp[i] = (ty + 1) * PW + (tx + 1);
-        xbase[i] = (unsigned)A_BASE + (unsigned)(base_pp[i] - PW - 1) * PITCH + (unsigned)lh * 16u;
+        xbase[i] = (unsigned)A_BASE + (unsigned)(ty * PW + tx) * PITCH + (unsigned)lh * 16u;   // top-left tap of the lane's pixel
     }
     unsigned wbase[2];   // k-step (0 / 1) of the half: piece (2 ks + lh) ^ ((row >> 2) & 3) of this lane's row; the 32-row block j and the slot are compile-time
 #pragma unroll
@@ -338,11 +342,92 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
             if (newseg) { ++seg; chunk = 0; } else ++chunk;
         }
     }
-    // ---- 1x1 tail (the fused skip conv of the decoder's conv_res1, pure 1x1 convs): centre tap, one half K-step per (chunk, channel half), NOT pipelined --
-    // each half-step fetches its own patch and half tile.  Correct and slow (two barriers and a memory round trip per 12 MFMAs of a wave): the planner
-    // keeps launches with a long 1x1 tail on conv_glds.hip, whose LDS-DMA stream serves them.
+    // ---- 1x1 tail (the fused skip conv of the decoder's conv_res1, pure 1x1 convs): centre tap, one half K-step per (64-channel chunk, channel half).
+    // Untransformed sources (every 1x1 segment of the U-Net; p.dma1x1 = the launcher's verdict): BOTH operands by LDS-DMA.  The 32 channels of the
+    // tile's 256 pixels (16 KB, 64-byte rows in MFMA column order, pieces swizzled like the weight rows) go into one of THREE stage buffers laid over
+    // the dead halo patches, two half-steps ahead, with the weight half tile of the same step behind them in the in-order vmcnt queue; one barrier
+    // per half-step, fragment reads not carried across it (the stage of step t + 1 may still be landing).  An operand without tap reuse costs six DMA
+    // pieces per 12 MFMAs of a wave in any structure: ~1.6x a 3x3 half-step.
+    // Transformed 1x1 sources: the unpipelined register path below (correct and slow; no such launch exists in the U-Net).
+    if constexpr (TAIL) {
+    if (n3 < p.kgroups && p.dma1x1) {
+        constexpr int STAGE = TPIX * 64, NSTG = 3;
+        static_assert(NSTG * STAGE <= 2 * A_BYTES, "stage buffers over the two halo patches");
+        int pseg = n3 > 0 ? seg + 1 : 0, pchunk = 0, phf = 0, pn = 1;
+        const T* psrc = nullptr;
+        unsigned poff[4];
+#define TDW_P_BEGIN()                                                                                                 \
+        {                                                                                                             \
+            const ConvSeg& sg_ = p.seg[pseg];                                                                         \
+            psrc = (const T*)sg_.src; pn = sg_.C / CHUNK;                                                             \
+            const int Hs_ = sg_.Hs, Ws_ = sg_.Ws, rs_ = sg_.resample, cs_ = sg_.cstride;                              \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+                const int e_ = tid + i_ * NTHR, row_ = e_ >> 2, j_ = (e_ & 3) ^ ((row_ >> 2) & 3);                    \
+                int img_, ty_, tx_;                                                                                   \
+                frag_pixel<TW, TPIX>(row_ & ~31, row_ & 31, img_, ty_, tx_);                                          \
+                const int y_ = y0 + ty_, x_ = x0 + tx_;                                                               \
+                /* a pixel outside the image is an MFMA column nobody stores: any readable address will do */         \
+                const int pix_ = (n0 < k_N && y_ < k_H && x_ < k_W) ? src_pixel(n0, y_, x_, Hs_, Ws_, rs_) : 0;       \
+                poff[i_] = (unsigned)(pix_ * cs_ + j_ * PER16) * (unsigned)sizeof(T);                                 \
+            }                                                                                                         \
+        }
+        unsigned sbuf_w = 0, sbuf_r = 0;   // stage buffer (byte offset) of the next stage to request / to read
+        const unsigned char* w1 = k_wpack + (size_t)co0 * 128 + (size_t)n3 * 9 * wstep;   // K-step of the half tile requested next
+        int w1h = 0;
+        // stage of the issue cursor + the weight half tile of the same step; the cursor stops on the last step (the loop issues unconditionally)
+#define TDW_P_ISSUE()                                                                                                 \
+        {                                                                                                             \
+            const unsigned long long sa_ = (unsigned long long)(psrc + (size_t)pchunk * CHUNK + phf * HALF);          \
+            const unsigned char* su_ = (const unsigned char*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sa_ >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)sa_)); \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { const unsigned m_ = (unsigned)A_BASE + sbuf_w + ldsw + (unsigned)i_ * 4096u; TD_GLDS16(poff[i_], su_, m_, 0); } \
+            sbuf_w += STAGE; if (sbuf_w == NSTG * STAGE) sbuf_w = 0;                                                  \
+            { const unsigned x_ = w1h ? 64u : 0u;                                                                     \
+              { const unsigned v_ = wvoff[0] ^ x_; const unsigned m_ = ldsw + wslot; TD_GLDS16(v_, w1, m_, 0); }      \
+              if constexpr (NBI > 1) { const unsigned v_ = voff1 ^ x_; const unsigned m_ = dump1 ? (unsigned)DUMP_BASE + ldsw - 2048u : ldsw + wslot + 4096u; TD_GLDS16(v_, w1, m_, 0); } } \
+            TDW_SLOT_NEXT(wslot)                                                                                      \
+            if (w1h) w1 += wstep;                                                                                     \
+            w1h ^= 1;                                                                                                 \
+            if (phf == 0) phf = 1;                                                                                    \
+            else if (pchunk + 1 < pn) { phf = 0; ++pchunk; }                                                          \
+            else if (pseg + 1 < k_nseg) { phf = 0; pchunk = 0; ++pseg; TDW_P_BEGIN(); }                               \
+        }
+        int nt1 = 0;   // half-steps of the tail
+        for (int sg = pseg; sg < k_nseg; ++sg) nt1 += 2 * (p.seg[sg].C / CHUNK);
+        TDW_P_BEGIN();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every wave is done with the halo patches and the ring
+        asm volatile("" ::: "memory");
+        wslot = 0; rslot = 0;
+        TDW_P_ISSUE();
+        TDW_P_ISSUE();
+        unsigned xb1[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) xb1[ks] = (unsigned)A_BASE + (unsigned)((wm * WM + l31) * 64 + (((ks * 2 + lh) ^ ((l31 >> 2) & 3)) << 4));
+        for (int t = 0; t < nt1; ++t) {
+            // in flight, oldest first: stage t, half tile t, stage t + 1, half tile t + 1
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NBI) : "memory");
+            __builtin_amdgcn_s_barrier();   // stage t and half tile t are visible; nobody reads stage t - 1 / half tile t - 1 any more
+            asm volatile("" ::: "memory");
+            TDW_P_ISSUE();
+#pragma unroll
+            for (int j_ = 0; j_ < NT; ++j_) wfA_[j_] = *(const u32x4*)(smem + (wbase[0] + rslot) + j_ * 2048);
+#pragma unroll
+            for (int i_ = 0; i_ < MT; ++i_) xfA_[i_] = *(const u32x4*)(smem + (xb1[0] + sbuf_r) + i_ * 2048);
+#pragma unroll
+            for (int j_ = 0; j_ < NT; ++j_) wfB_[j_] = *(const u32x4*)(smem + (wbase[1] + rslot) + j_ * 2048);
+#pragma unroll
+            for (int i_ = 0; i_ < MT; ++i_) xfB_[i_] = *(const u32x4*)(smem + (xb1[1] + sbuf_r) + i_ * 2048);
+            TDW_SLOT_NEXT(rslot)
+            sbuf_r += STAGE; if (sbuf_r == NSTG * STAGE) sbuf_r = 0;
+            TDW_FRAG_MFMA(wfA_, xfA_);
+            TDW_FRAG_MFMA(wfB_, xfB_);
+        }
+#undef TDW_P_ISSUE
+#undef TDW_P_BEGIN
+    } else
 #ifndef TDW_NO_TAIL
-    if (n3 < p.kgroups) {
+    if (n3 < p.kgroups) {   // (register-staged, unpipelined)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two half tiles fetched past the end of the 3x3 part
         const unsigned char* w1 = k_wpack + (size_t)co0 * 128 + (size_t)n3 * 9 * wstep;
         int s1 = n3 == 0 ? 0 : (chunk == 0 && seg > 0 ? seg : seg + 1);
@@ -374,7 +459,10 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
             }
         }
     }
+#else
+    {}
 #endif
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-fetched tail tiles must not land in a successor's LDS
 #undef TDW_TOFF
 #undef TDW_HS
@@ -402,6 +490,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
 #pragma unroll
     for (int q = 0; q < NRX; ++q) rx[q] = u32x4{0u, 0u, 0u, 0u};
     if (has_res) {
+        if (!r_want) TDW_R_ADDR()   // (the TAIL instantiation: the run addresses are made here, not carried across the K loop)
         if (!r_pref) TDW_LOAD_R()   // the launch ended in 1x1 K-groups: nothing was requested yet
         if constexpr (MT * NU > A_ITERS) {
 #pragma unroll
@@ -421,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
 #pragma unroll
         for (int j = 0; j < NT; ++j) ssj[j] = 0.f;
         if (ok) {
-            const float rn = e_hrss ? s_rn[base_pp[i]] : 1.f;
+            const float rn = e_hrss ? s_rn[(ty + 1) * PW + (tx + 1)] : 1.f;
             {
                 const size_t pix = ((size_t)n * k_H + y) * k_W + x;
                 T* orow = (T*)p.out + pix * e_ocs + co0 + 8 * lh;
@@ -491,8 +580,8 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
 #undef TDW_LOAD_R
 }
 
-template <typename T, int BN>
-static hipError_t launch_glds_wide_cfg(const ConvParams& p, hipStream_t st) {
+template <typename T, int BN, bool TAIL>
+static hipError_t launch_glds_wide_cfg2(const ConvParams& p, hipStream_t st) {
     constexpr int NPATCH = 18 * 18;
     constexpr size_t RING_BYTES = 4 * (size_t)(BN * 64) + ((BN * 64) % 4096 ? 2048 : 0);   // four exact slots (+ the dump area of the rowless pieces, BN 96)
     constexpr size_t LDS = RING_BYTES + 2 * (size_t)NPATCH * 80 + (NPATCH * 4 + 15) / 16 * 16 + (size_t)BN * 4;
@@ -503,11 +592,13 @@ static hipError_t launch_glds_wide_cfg(const ConvParams& p, hipStream_t st) {
     for (int s = 0; s < p.nseg; ++s) { if (p.seg[s].taps == 9 && seen1) return hipErrorInvalidValue; if (p.seg[s].taps != 9) seen1 = true; }
     ConvParams pd = p;
     for (int s = p.nseg; s < 3; ++s) { pd.seg[s].C = 0; pd.seg[s].taps = 0; }   // (the kernel reads all three descriptors in one burst)
+    pd.dma1x1 = 1;   // the 1x1 tail by LDS-DMA unless a 1x1 source wants a transform at staging
+    for (int s = 0; s < p.nseg; ++s) if (p.seg[s].taps != 9 && p.seg[s].xform != 0) pd.dma1x1 = 0;
     const int mtiles = p.tiles_x * p.tiles_y * p.img_groups, grid = p.n_ntiles * mtiles;
     if (grid <= 0 || (long long)grid * std::max(mtiles, p.n_ntiles) >= ((long long)1 << 32)) return hipErrorInvalidValue;
     pd.sb_d0 = mtiles; pd.sb_m0 = td_magic(mtiles); pd.sb_d1 = p.n_ntiles; pd.sb_m1 = td_magic(p.n_ntiles); pd.sb_m2 = td_magic(p.tiles_x); pd.sb_m3 = td_magic(p.tiles_y);
     pd.sb_grid = grid; pd.sb_grid8 = (grid & 7) == 0 ? (unsigned)grid >> 3 : 0u;
-    auto kern = conv_glds_kernel_wide<T, BN>;
+    auto kern = conv_glds_kernel_wide<T, BN, TAIL>;
     static bool attr_set[64] = {};
     int dev_ = 0; (void)hipGetDevice(&dev_);
     if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_]) {
@@ -517,6 +608,13 @@ static hipError_t launch_glds_wide_cfg(const ConvParams& p, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, pd);
     return hipGetLastError();
+}
+
+template <typename T, int BN>
+static hipError_t launch_glds_wide_cfg(const ConvParams& p, hipStream_t st) {
+    bool tail = false;
+    for (int s = 0; s < p.nseg; ++s) if (p.seg[s].taps != 9) tail = true;
+    return tail ? launch_glds_wide_cfg2<T, BN, true>(p, st) : launch_glds_wide_cfg2<T, BN, false>(p, st);
 }
 
 // dtype: 1 bf16, 2 fp16; bn: 64 / 96 (a 128-cout tile needs 86 KB of LDS and 256+ registers: one workgroup per CU, which is what this flavour exists to avoid).  16-wide maps only, tiles_y = ceil(H / 16), tiles_x = ceil(W / 16), img_groups = N, no split-K.

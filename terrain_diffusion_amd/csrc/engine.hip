@@ -674,7 +674,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
     static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn",
                                                "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
                                                "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups", "glds_round_aware", "walk_alternate", "glds_tiny", "glds_dma1x1", "splitk_weighted",
-                                               "sb", "sb_target_wgs", "sb_mt", "sb_nt", "sb_order", "sb_max_glds_wgs", "sb_splitk", "sb_splitk_wgs", "sb_splitk_max", "s16", "s16_min_wgs", "sb_m4", "glds_wide", "glds_wide_min_wgs"};
+                                               "sb", "sb_target_wgs", "sb_mt", "sb_nt", "sb_order", "sb_max_glds_wgs", "sb_splitk", "sb_splitk_wgs", "sb_splitk_max", "s16", "s16_min_wgs", "sb_m4", "glds_wide", "glds_wide_min_wgs", "glds_wide_tail"};
     std::string key = std::to_string(N) + "_" + std::to_string(H) + "_" + std::to_string(W);
     for (const char* o : kPlanOptions) key += "_" + std::to_string((long long)u->eng->option(o, -7));
     if (lane) key += "_lane" + std::to_string(lane);   // a second, independent activation set of the same shape (concurrent half-batches)
@@ -823,13 +823,13 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                 // patch -- half the weight bytes per MFMA through the CU's L2 -> LDS path, 0.6x the LDS fragment reads, half as many workgroup
                 // prologues / epilogue drains, no restage barrier.  Taken where its grid still gives every CU slot >= "glds_wide_min_wgs" / 512 workgroups
                 // (the 64x64, 32x32 and 16x16 levels of a 64-window batch -- 384 workgroups of 256 pixels there are one round on 3/4 of the slots where 768 of 128 pixels
-                // are one and a half rounds: +0.9 % on the bench line, tools/r06_exp3.sh --, the decoder's 512x512 / 256x256 levels) for launches it serves at full speed: pure
-                // 3x3 K (its 1x1 tail is not pipelined), 16-bit output in 16-byte runs.  Another K order than the other tiles (channel half outside the
+                // are one and a half rounds: +0.9 % on the bench line, tools/r06_exp3.sh --, the decoder's 512x512 / 256x256 levels) for launches it serves at full speed: 3x3
+                // K-segments, optionally followed by untransformed 1x1 segments (streamed by LDS-DMA), 16-bit output in 16-byte runs.  Another K order than the other tiles (channel half outside the
                 // taps): never in batch_invariant mode, where the choice must not depend on the batch.  Option "glds_wide": 0 never, 1 this rule, 2 wherever legal.
                 {
                     const int64_t wmode = u->eng->option("glds_wide", 1);
-                    bool pure3 = true;
-                    for (const SegSpec& sg : segs) if (sg.taps != 9) pure3 = false;
+                    bool pure3 = true;   // (a 1x1 tail is served at speed when its sources need no transform at staging: both operands by LDS-DMA; "glds_wide_tail" = 0 keeps such launches on conv_glds)
+                    for (const SegSpec& sg : segs) if (sg.taps != 9 && (sg.xform != 0 || u->eng->option("glds_wide_tail", 1) == 0)) pure3 = false;
                     const int bnw = cw.cout_pad % 96 == 0 ? 96 : (cw.cout_pad % 64 == 0 ? 64 : 0);
                     const int64_t wgs_w = bnw ? tiles(16, 1) * (cw.cout_pad / bnw) : 0;
                     if (wmode != 0 && !inv && fv < 0 && fbn == 0 && !op.narrow && p.ksplit == 1 && bnw && !out_f32 && (cw.cout & 7) == 0 && p.nseg <= 3 && (pure3 || wmode == 2) &&
@@ -1267,7 +1267,7 @@ static const char* const kKnownOptions[] = {
     "plan_cache_mb", "plan_cache_max",
     // plan builder (speed only, or test hooks that force a tile shape; all part of the plan-cache key)
     "attn_mfma", "bn128_min_wgs", "glds", "glds_bn", "glds_bn64", "glds_dma1x1", "glds_min_wgs", "glds_round_aware", "glds_small_max_groups",
-    "glds_splitk", "glds_splitk_from_groups", "glds_splitk_max", "glds_splitk_min_groups", "glds_tiny", "glds_variant", "glds_wide", "glds_wide_min_wgs",
+    "glds_splitk", "glds_splitk_from_groups", "glds_splitk_max", "glds_splitk_min_groups", "glds_tiny", "glds_variant", "glds_wide", "glds_wide_min_wgs", "glds_wide_tail",
     "producer_act", "s16", "s16_min_wgs", "sb", "sb_m4", "sb_max_glds_wgs", "sb_mt", "sb_nt", "sb_order", "sb_splitk", "sb_splitk_max", "sb_splitk_wgs", "sb_target_wgs", "splitk",
     "splitk_target_wgs", "splitk_weighted", "walk_alternate"};
 int td_engine_set_option(td_engine* e, const char* key, int64_t value) {
