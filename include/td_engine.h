@@ -92,7 +92,7 @@ int td_engine_set_stream(td_engine* e, void* hip_stream);
  *   "s16"=0/1/2 (deep-level latency flavour, conv_s16.hip: never / where conv_sb would split K over workgroups and the 16-cout grid reaches
  *   "s16_min_wgs" workgroups / wherever conv_sb applies),
  *   "glds_wide"=0/1/2 (wide tile of the LDS-DMA flavour, conv_glds_wide.hip: never / pure-3x3 launches whose 256-pixel grid reaches "glds_wide_min_wgs"
- *   (384) workgroups / wherever it is legal), "glds_wide_tail"=0/1 (launches with a 1x1 tail on the wide tile).
+ *   (384) workgroups / wherever it is legal), "glds_wide_tail"=0/1/2 (launches with an untransformed 1x1 tail on the wide tile: never / on its 64-cout tile (the decoder model) / always).
  * Test hooks that force a tile shape wherever it is legal: "glds_variant"=-1/0/1, "glds_bn"=0/64/96/128, "sb_mt"=0/1/2/4, "sb_nt"=0/1/2. */
 int td_engine_set_option(td_engine* e, const char* key, int64_t value);
 

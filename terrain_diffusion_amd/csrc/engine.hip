@@ -828,9 +828,14 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                 // taps): never in batch_invariant mode, where the choice must not depend on the batch.  Option "glds_wide": 0 never, 1 this rule, 2 wherever legal.
                 {
                     const int64_t wmode = u->eng->option("glds_wide", 1);
-                    bool pure3 = true;   // (a 1x1 tail is served at speed when its sources need no transform at staging: both operands by LDS-DMA; "glds_wide_tail" = 0 keeps such launches on conv_glds)
-                    for (const SegSpec& sg : segs) if (sg.taps != 9 && (sg.xform != 0 || u->eng->option("glds_wide_tail", 1) == 0)) pure3 = false;
                     const int bnw = cw.cout_pad % 96 == 0 ? 96 : (cw.cout_pad % 64 == 0 ? 64 : 0);
+                    // A 1x1 tail (the decoder blocks' fused skip conv) is streamed by LDS-DMA on the wide tile as well, when its sources need no transform at staging.
+                    // Measured (tools/r06_exp7.sh): level with conv_glds's stream on the base model's 192 / 384-cout layers (360.7 vs 360.8, 320.1 vs 320.5, 267.8 vs
+                    // 266.9 us), a loss at the 16x16 level (134 -> 145 us) and -1.4 % on the bench line with two lanes; +10 % on the decoder model's 64-cout layers
+                    // (268 -> 242 us) and +1.7 % on the cascade.  Hence: tails on the wide tile for the 64-cout tile only.  "glds_wide_tail": 0 never, 1 this rule, 2 always.
+                    const int64_t tmode = u->eng->option("glds_wide_tail", 1);
+                    bool pure3 = true;
+                    for (const SegSpec& sg : segs) if (sg.taps != 9 && (sg.xform != 0 || tmode == 0 || (tmode == 1 && bnw != 64))) pure3 = false;
                     const int64_t wgs_w = bnw ? tiles(16, 1) * (cw.cout_pad / bnw) : 0;
                     if (wmode != 0 && !inv && fv < 0 && fbn == 0 && !op.narrow && p.ksplit == 1 && bnw && !out_f32 && (cw.cout & 7) == 0 && p.nseg <= 3 && (pure3 || wmode == 2) &&
                         (wmode == 2 || wgs_w >= u->eng->option("glds_wide_min_wgs", 384))) {
@@ -1240,7 +1245,8 @@ int td_engine_create(int device_id, td_engine** out) {
 void td_engine_destroy(td_engine* e) {
     if (!e) return;
     DevGuard dg_(e->device);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
+    // (the engine's OWN stream: e->stream may be the caller's -- td_engine_set_stream -- and is not ours to destroy)
+    if (e->own_stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->own_stream); }
     if (e->stream2) (void)hipStreamDestroy(e->stream2);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
