@@ -32,9 +32,6 @@
 
 namespace td {
 
-#ifndef TDW_XFORM_ON
-#define TDW_XFORM_ON 1
-#endif
 #ifdef TD_TRACE
 #define TDW_T(v) unsigned long long v = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define TDW_TACC(acc, a, b) acc += (b) - (a)
@@ -193,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
         _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) {                                    \
             if (it_ < 5 || tid < (NPATCH - 5 * 64) * 4) {                                              \
                 u32x4 v_ = aoff[it_] >= 0 ? av[it_] : u32x4{0u, 0u, 0u, 0u};                           \
-                if (TDW_XFORM_ON && seg_xform != 0 && aoff[it_] >= 0) {                                \
+                if (seg_xform != 0 && aoff[it_] >= 0) {                                \
                     float s_ = seg_scale;                                                              \
                     if (seg_xform == 2) s_ *= s_rn[(tid >> 2) + it_ * 64];                             \
                     v_ = xform_piece<T>(v_, s_);                                                       \
@@ -425,9 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
         }
 #undef TDW_P_ISSUE
 #undef TDW_P_BEGIN
-    } else
-#ifndef TDW_NO_TAIL
-    if (n3 < p.kgroups) {   // (register-staged, unpipelined)
+    } else if (n3 < p.kgroups) {   // (register-staged, unpipelined)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two half tiles fetched past the end of the 3x3 part
         const unsigned char* w1 = k_wpack + (size_t)co0 * 128 + (size_t)n3 * 9 * wstep;
         int s1 = n3 == 0 ? 0 : (chunk == 0 && seg > 0 ? seg : seg + 1);
@@ -459,9 +454,6 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
             }
         }
     }
-#else
-    {}
-#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-fetched tail tiles must not land in a successor's LDS
 #undef TDW_TOFF
@@ -619,9 +611,6 @@ static hipError_t launch_glds_wide_cfg(const ConvParams& p, hipStream_t st) {
 
 // dtype: 1 bf16, 2 fp16; bn: 64 / 96 (a 128-cout tile needs 86 KB of LDS and 256+ registers: one workgroup per CU, which is what this flavour exists to avoid).  16-wide maps only, tiles_y = ceil(H / 16), tiles_x = ceil(W / 16), img_groups = N, no split-K.
 hipError_t launch_conv_glds_wide(const ConvParams& p, int dtype, int bn, hipStream_t st) {
-#ifdef TDW_ONLY96   // (development builds: one instantiation)
-    return dtype == 1 && bn == 96 ? launch_glds_wide_cfg<__bf16, 96>(p, st) : hipErrorInvalidValue;
-#endif
     if (dtype == 2) {
         if (bn == 96) return launch_glds_wide_cfg<_Float16, 96>(p, st);
         if (bn == 64) return launch_glds_wide_cfg<_Float16, 64>(p, st);

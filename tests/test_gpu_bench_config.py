@@ -474,7 +474,19 @@ def test_decoder_window_at_real_size(td, dtype, tol):
     lat_win = torch.cat([torch.from_numpy(rng.standard_normal(33, (5, 64, 64))) * wl, wl[None]])
     src = InfiniteTensor((6, None, None), lambda ctx: lat_win, TensorWindow(size=(6, 64, 64), stride=(6, 48, 48)), tensor_id="lat_src512")
     ds = build_decoder_stage(md, src, seed=1234, tile_size=512, tile_stride=384)
-    out = ds.f([(0, 1, -2)], [lat_win])[0]
+    from terrain_diffusion_amd.engine import get_engine
+    eng = get_engine("cuda")
+    eng.set_option("profile", 1); eng.profile_read(reset=True)
+    try:
+        out = ds.f([(0, 1, -2)], [lat_win])[0]
+        labels = [l for l, _, _ in eng.profile_ops()]
+    finally:
+        eng.profile_read(reset=True); eng.set_option("profile", 0)
+    if dtype != "fp32":
+        # round 6: the 64-cout levels of the decoder run on the wide tile of the LDS-DMA conv, 1x1 tails (the dec blocks' fused skip conv) included --
+        # the LDS-DMA-streamed tail of conv_glds_wide.hip is what this window exercises against the oracle
+        wide = [l for l in labels if " f2w " in l]
+        assert any("dec.512x512_block" in l and "conv_res1" in l for l in wide) and any("enc.512x512_block" in l for l in wide), labels[:8]
     ref = stages.decoder_inference(OracleUnet(DECODER_CONFIG, sd), (0, 1, -2), lat_win, seed=1234, tile_size=512, tile_stride=384)
     assert out.shape == ref.shape == (2, 512, 512)
     assert torch.equal(out[1], ref[1])                                          # blend window: bit-exact
