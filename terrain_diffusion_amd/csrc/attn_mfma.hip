@@ -39,10 +39,21 @@ namespace td {
 
 struct AttnStrides { long b, h, t, c; };  // element strides of (batch, head, token, channel)
 
+// Round 6, "folded softmax bookkeeping" (head dims <= 80: the terrain U-Net's 64, SD-v1.5's 40 / 80).  Two of the three per-score VALU passes of the online softmax move
+// to the matrix pipe, which idles 70 % of the time at these head dims:
+//   * the subtraction of the reference point m rides in ONE EXTRA CHANNEL of the Q K^T contraction: K carries 1.0 there, Q carries -m (bf16; m is kept bf16-
+//     representable, so numerator and denominator see exactly the same reference) -- the MFMA delivers s - m;
+//   * the row sum l rides in ONE EXTRA ROW of V^T (1.0 for real keys): that row of O^T accumulates the sum of the bf16-rounded probabilities -- the values the
+//     numerator contracts, so the two are consistent by construction (the fp32 sum of round 3's "lean softmax" was not).
+// d = 40 has the room in its padding (48 contraction channels, 64 V^T rows); d = 64 / 80 pay one more k-step of Q K^T and one more 32-row block of V^T P^T.
+static inline bool attn_fold(int D) { return D <= 80; }
+static inline int attn_dp(int D) { return attn_fold(D) ? (D + 16) / 16 * 16 : (D + 15) / 16 * 16; }
+static inline int attn_dm(int D) { return attn_fold(D) ? (D + 32) / 32 * 32 : (D + 31) / 32 * 32; }
+
 // grid (ceil(L / 64), H, B) x 3 roles via blockIdx.x ranges is overkill: one launch per operand (which = 0 q, 1 k, 2 v)
 template <typename TIN>
 __global__ __launch_bounds__(256) void attn_pack_kernel(const TIN* __restrict__ src, AttnStrides st, int L, int D, int Dp, int Dm, int Lkp, int which, int normalize,
-                                                        float post_scale, __bf16* __restrict__ dst) {
+                                                        float post_scale, __bf16* __restrict__ dst, int fold) {
     // one wave per token: lanes stride over channels
     const int tok = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
     if (tok >= (which == 2 ? Lkp : L)) return;
@@ -62,15 +73,16 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(const TIN* __restrict__ 
         inv = 1.f / (1e-4f + sqrtf(ss) / sqrtf((float)D));
     }
     inv *= post_scale;  // Q carries the softmax scale * log2(e): the flash kernel's logits come out of the MFMA ready for exp2 (one multiply per score saved)
+    // fold != 0: channel D of K = 1.0 (Q's starts at 0 = reference point 0), row D of V^T = 1.0 for real keys (see attn_fold)
     if (which < 2) {
         __bf16* out = dst + (((long)b * H + h) * L + tok) * Dp;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { const int c = lane + 64 * j; if (c < Dp) out[c] = (__bf16)(v[j] * inv); }
+        for (int j = 0; j < 3; ++j) { const int c = lane + 64 * j; if (c < Dp) out[c] = (fold && which == 1 && c == D) ? (__bf16)1.f : (__bf16)(v[j] * inv); }
     } else {
         const int pk = (tok & ~15) | (tok & 3) | (((tok >> 3) & 1) << 2) | (((tok >> 2) & 1) << 3);  // key order inside a group of 16 (see header)
         __bf16* out = dst + ((long)b * H + h) * Dm * Lkp + pk;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { const int c = lane + 64 * j; if (c < Dm) out[(long)c * Lkp] = (__bf16)(v[j] * inv); }
+        for (int j = 0; j < 3; ++j) { const int c = lane + 64 * j; if (c < Dm) out[(long)c * Lkp] = (fold && c == D && real) ? (__bf16)1.f : (__bf16)(v[j] * inv); }
     }
 }
 
@@ -99,12 +111,18 @@ __global__ __launch_bounds__(256) void attn_pack_qkv64_kernel(const TIN* __restr
     }
     inv[0] *= qscale; inv[1] *= 1.f; inv[2] *= 1.f;
     const long bh = (long)b * H + h;
+    constexpr int Dp = 80, Dm = 96;   // attn_dp(64), attn_dm(64): one extra contraction channel (K: 1.0, Q: the reference point, 0 at the start), one extra V^T row (1.0 for real keys)
     if (real) {
-        Qp[(bh * L + tok) * 64 + lane] = (__bf16)(x[0] * inv[0]);
-        Kp[(bh * L + tok) * 64 + lane] = (__bf16)(x[1] * inv[1]);
+        Qp[(bh * L + tok) * Dp + lane] = (__bf16)(x[0] * inv[0]);
+        Kp[(bh * L + tok) * Dp + lane] = (__bf16)(x[1] * inv[1]);
+        if (lane < Dp - 64) {
+            Qp[(bh * L + tok) * Dp + 64 + lane] = (__bf16)0.f;
+            Kp[(bh * L + tok) * Dp + 64 + lane] = lane == 0 ? (__bf16)1.f : (__bf16)0.f;
+        }
     }
     const int pk = (tok & ~15) | (tok & 3) | (((tok >> 3) & 1) << 2) | (((tok >> 2) & 1) << 3);  // key order inside a group of 16 (see header)
-    Vt[(bh * 64 + lane) * Lkp + pk] = (__bf16)(x[2] * inv[2]);   // padded keys: zeros
+    Vt[(bh * Dm + lane) * Lkp + pk] = (__bf16)(x[2] * inv[2]);   // padded keys: zeros
+    if (lane < Dm - 64) Vt[(bh * Dm + 64 + lane) * Lkp + pk] = (lane == 0 && real) ? (__bf16)1.f : (__bf16)0.f;
 }
 
 #ifndef TD_ATTN_THR
@@ -117,7 +135,7 @@ __global__ __launch_bounds__(256) void attn_pack_qkv64_kernel(const TIN* __restr
 #endif
 
 // DP16 = Dp / 16 (k-steps of Q K^T), DM32 = Dm / 32 (row blocks of O^T)
-template <int DP16, int DM32, int NW>
+template <int DP16, int DM32, int NW, bool FOLD>
 __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __restrict__ Qp, const __bf16* __restrict__ Kp, const __bf16* __restrict__ Vt, float* __restrict__ out_f32,
                                                         __bf16* __restrict__ out_b16, AttnStrides ost, int Lq, int Lk, int Lkp, int D) {
     constexpr int Dp = DP16 * 16, Dm = DM32 * 32, TK = 64;
@@ -144,7 +162,7 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
     for (int d = 0; d < DM32; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -3.0e38f, l_run = 0.f;
+    float m_run = -3.0e38f, l_run = 0.f, m_ref = 0.f;   // FOLD: m_ref = the query's reference point (bf16-representable), m_run = its running maximum relative to it
     const __bf16* kbase = Kp + ((long)b * H + h) * Lk * Dp;
     const __bf16* vbase = Vt + ((long)b * H + h) * Dm * Lkp;
     constexpr int KPIECES = TK * (Dp / 8), VPIECES = Dm * (TK / 8);
@@ -223,7 +241,8 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
         // ---- online softmax for this lane's query: keys of register r of block kb = k0 + 32 kb + 8 (r / 4) + 4 lh + r % 4.
         // The softmax is what bounds this kernel at small head dims (d = 40: 14 MFMAs = 448 matrix cycles against ~850 VALU cycles per tile
         // in round 2), so it is kept lean: no scaling multiply (folded into Q), the key mask only on the last, ragged tile, three-input
-        // maxima, packed fp32 subtract / sum, one v_cvt_pk per two probabilities.
+        // maxima, one v_cvt_pk per two probabilities -- and, FOLD (round 6), neither the subtraction of the reference point nor the row sum
+        // (both on the matrix pipe: attn_fold).
         if (k0 + TK > Lk) {  // wave-uniform: only the last tile of a ragged key length
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -239,17 +258,61 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
 #pragma unroll
             for (int r = (kb == 0 ? 2 : 0); r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[kb][r]), s[kb][r + 1]);   // v_max3_f32
         mt = fmaxf(mt, __shfl_xor(mt, 32));
+        u32x4 pf[4];  // B fragments of the four 16-key steps: 8 probabilities each, already in contraction order
+        bool moved;
+        float alpha = 1.f;
+        if constexpr (FOLD) {
+            // s already is (logit - m_ref): the reference point m_ref of this lane's query rides in channel D of its Q fragment.  It moves -- for the whole
+            // wave -- when some query's scores outgrew it by 2^THR, or when a query's running maximum lies so far BELOW it that the probabilities would lose
+            // their exponent range (fp32 / bf16 keep relative precision down to 2^-126; 2^-64 is the margin).  The new reference is the query's running
+            // maximum, rounded to bf16 (it must be exactly what the MFMA subtracts).
+            m_run = fmaxf(m_run, mt);   // (FOLD: the running maximum RELATIVE to m_ref)
+            moved = __builtin_amdgcn_ballot_w64(mt > (float)TD_ATTN_THR || m_run < -64.f) != 0;
+            if (moved) {
+                const float m_new = (float)(__bf16)(m_ref + m_run), delta = m_new - m_ref;   // exact: both bf16 values
+                alpha = __builtin_amdgcn_exp2f(-delta);
+                m_ref = m_new; m_run -= delta;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kb][r] -= delta;   // this tile's scores were contracted against the old reference
+                // the Q fragment's reference channel: element D % 8 of the lanes whose half holds channels 8 (D / 8 % 2) ... of k-step D / 16
+                const unsigned nb = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)(-m_new));
+                const int e16 = D & 15, ksm = D >> 4;
+                if (lh == (e16 >> 3)) {
+                    const int dw = (e16 & 7) >> 1, hi = e16 & 1;
+#pragma unroll
+                    for (int ks = 0; ks < DP16; ++ks)
+                        if (ks == ksm) {
+#pragma unroll
+                            for (int w_ = 0; w_ < 4; ++w_)
+                                if (w_ == dw) qf[ks][w_] = hi ? ((qf[ks][w_] & 0x0000ffffu) | (nb << 16)) : ((qf[ks][w_] & 0xffff0000u) | nb);
+                        }
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    bf16x8 pb;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        pb[e] = (__bf16)__builtin_amdgcn_exp2f(s[kb][jj * 8 + e]);
+                        pb[e + 1] = (__bf16)__builtin_amdgcn_exp2f(s[kb][jj * 8 + e + 1]);
+                    }
+                    pf[kb * 2 + jj] = __builtin_bit_cast(u32x4, pb);
+                }
+        } else {
         // Deferred maximum (TD_ATTN_THR, in log2 units): the reference point m of a query only follows its running maximum when SOME query of
         // the wave has outgrown its own by more than 2^THR -- then O and the denominator of the whole wave are rescaled; otherwise m stays and the
         // probabilities of this tile are at most 2^THR instead of 1 (fp32 accumulators, bf16 relative precision: nothing overflows, numerator
         // and denominator refer to the same m).  THR = 0 is the textbook form (rescale whenever any maximum grew: most tiles of random data).
-        const bool moved = __builtin_amdgcn_ballot_w64(mt > m_run + (float)TD_ATTN_THR) != 0;
+        moved = __builtin_amdgcn_ballot_w64(mt > m_run + (float)TD_ATTN_THR) != 0;
         const float m_new = moved ? fmaxf(m_run, mt) : m_run;
-        const float alpha = moved ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.f;
+        alpha = moved ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.f;
         // plain (unpacked) fp32 subtracts and adds: beside the partner wave's MFMAs a v_pk_add_f32 costs ~13 cycles more than a plain VALU op
         // (MI355X_MICROARCH.md); two running sums (even / odd elements) keep the summation order of the packed form
         float psum_e = 0.f, psum_o = 0.f;
-        u32x4 pf[4];  // B fragments of the four 16-key steps: 8 probabilities each, already in contraction order
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -266,6 +329,7 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
             }
         l_run = l_run * alpha + (psum_e + psum_o);
         m_run = m_new;
+        }
 #ifdef TD_ATTN_TRACE
         asm volatile("s_nop 0" :: "v"(pf[3]), "v"(l_run));
 #endif
@@ -297,7 +361,21 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
     }
     out_b16 = nullptr;
 #endif
-    const float linv = 1.f / (l_run + __shfl_xor(l_run, 32));
+    float linv;
+    if constexpr (FOLD) {
+        // row D of O^T is the denominator: register r, lane half lhl of 32-row block D / 32 (row = 8 (r / 4) + 4 lh + r % 4)
+        const int rho = D & 31, lhl = (rho >> 2) & 1, rl = (rho >> 3) * 4 + (rho & 3);
+        float lsum = 0.f;
+#pragma unroll
+        for (int d = 0; d < DM32; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (d == (D >> 5) && r == rl) lsum = o[d][r];
+        const float other = __shfl_xor(lsum, 32);
+        linv = 1.f / (lh == lhl ? lsum : other);
+        (void)l_run; (void)m_ref;
+    } else {
+        linv = 1.f / (l_run + __shfl_xor(l_run, 32));
+    }
     if (qok) {
 #pragma unroll
         for (int d = 0; d < DM32; ++d)
@@ -320,10 +398,10 @@ template <typename TIN>
 static hipError_t attn_pack(const TIN* q, const TIN* k, const TIN* v, AttnStrides sq, AttnStrides sk, AttnStrides sv, int B, int H, int Lq, int Lk, int D, int normalize,
                             float scale, __bf16* Qp, __bf16* Kp, __bf16* Vt, hipStream_t st) {
     const float qscale = scale * 1.4426950408889634f;  // folded into Q (see attn_pack_kernel)
-    const int Dp = (D + 15) / 16 * 16, Dm = (D + 31) / 32 * 32, Lkp = (Lk + 63) / 64 * 64;
-    hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lq + 3) / 4, H, B), dim3(256), 0, st, q, sq, Lq, D, Dp, Dm, Lkp, 0, normalize, qscale, Qp);
-    hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lk + 3) / 4, H, B), dim3(256), 0, st, k, sk, Lk, D, Dp, Dm, Lkp, 1, normalize, 1.f, Kp);
-    hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lkp + 3) / 4, H, B), dim3(256), 0, st, v, sv, Lk, D, Dp, Dm, Lkp, 2, normalize, 1.f, Vt);
+    const int Dp = attn_dp(D), Dm = attn_dm(D), Lkp = (Lk + 63) / 64 * 64, fold = attn_fold(D) ? 1 : 0;
+    hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lq + 3) / 4, H, B), dim3(256), 0, st, q, sq, Lq, D, Dp, Dm, Lkp, 0, normalize, qscale, Qp, fold);
+    hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lk + 3) / 4, H, B), dim3(256), 0, st, k, sk, Lk, D, Dp, Dm, Lkp, 1, normalize, 1.f, Kp, fold);
+    hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lkp + 3) / 4, H, B), dim3(256), 0, st, v, sv, Lk, D, Dp, Dm, Lkp, 2, normalize, 1.f, Vt, fold);
     return hipGetLastError();
 }
 
@@ -336,22 +414,25 @@ static hipError_t attn_pack_qkv64(const TIN* qkv, long tok_stride, int B, int H,
 
 static hipError_t attn_mfma(const __bf16* Qp, const __bf16* Kp, const __bf16* Vt, float* out_f32, __bf16* out_b16, AttnStrides ost, int B, int H, int Lq, int Lk, int D,
                             hipStream_t st) {
-    const int Dp16 = (D + 15) / 16, Dm32 = (D + 31) / 32, Lkp = (Lk + 63) / 64 * 64;
+    const int Dp16 = attn_dp(D) / 16, Dm32 = attn_dm(D) / 32, Lkp = (Lk + 63) / 64 * 64;
+    const bool fold = attn_fold(D);
     // 8 waves (256 queries) per workgroup when there are enough queries to fill the chip that way: the K / V^T tile is staged once per workgroup
     static const long big_min = getenv("TD_ATTN_BIG_MIN") ? atol(getenv("TD_ATTN_BIG_MIN")) : 256;   // A/B hook (tools/attn_bench.py)
     const bool big = (long)((Lq + 255) / 256) * H * B >= big_min;
     const dim3 grid(big ? (Lq + 255) / 256 : (Lq + 127) / 128, H, B), blk(big ? 512 : 256);
-#define TD_ATTN_CASE(A, M) if (Dp16 == A && Dm32 == M) {                                                                                        \
-        if (big) hipLaunchKernelGGL((attn_mfma_kernel<A, M, 8>), grid, blk, 0, st, Qp, Kp, Vt, out_f32, out_b16, ost, Lq, Lk, Lkp, D);           \
-        else hipLaunchKernelGGL((attn_mfma_kernel<A, M, 4>), grid, blk, 0, st, Qp, Kp, Vt, out_f32, out_b16, ost, Lq, Lk, Lkp, D);               \
+#define TD_ATTN_CASE(A, M, F) if (Dp16 == A && Dm32 == M && fold == F) {                                                                        \
+        if (big) hipLaunchKernelGGL((attn_mfma_kernel<A, M, 8, F>), grid, blk, 0, st, Qp, Kp, Vt, out_f32, out_b16, ost, Lq, Lk, Lkp, D);        \
+        else hipLaunchKernelGGL((attn_mfma_kernel<A, M, 4, F>), grid, blk, 0, st, Qp, Kp, Vt, out_f32, out_b16, ost, Lq, Lk, Lkp, D);            \
         return hipGetLastError(); }
-    TD_ATTN_CASE(1, 1) TD_ATTN_CASE(2, 1) TD_ATTN_CASE(3, 2) TD_ATTN_CASE(4, 2) TD_ATTN_CASE(5, 3) TD_ATTN_CASE(6, 3) TD_ATTN_CASE(7, 4) TD_ATTN_CASE(8, 4) TD_ATTN_CASE(9, 5) TD_ATTN_CASE(10, 5)
+    // head dims <= 80 (folded softmax bookkeeping: D + 1 contraction channels / V^T rows) ... 81 - 160 (plain)
+    TD_ATTN_CASE(1, 1, true) TD_ATTN_CASE(2, 1, true) TD_ATTN_CASE(3, 2, true) TD_ATTN_CASE(4, 2, true) TD_ATTN_CASE(5, 3, true) TD_ATTN_CASE(6, 3, true)
+    TD_ATTN_CASE(6, 3, false) TD_ATTN_CASE(7, 4, false) TD_ATTN_CASE(8, 4, false) TD_ATTN_CASE(9, 5, false) TD_ATTN_CASE(10, 5, false)
 #undef TD_ATTN_CASE
     return hipErrorInvalidValue;
 }
 
 static size_t attn_workspace_elems(int B, int H, int Lq, int Lk, int D, size_t* qn, size_t* kn, size_t* vn) {
-    const size_t Dp = (D + 15) / 16 * 16, Dm = (D + 31) / 32 * 32, Lkp = (Lk + 63) / 64 * 64;
+    const size_t Dp = attn_dp(D), Dm = attn_dm(D), Lkp = (Lk + 63) / 64 * 64;
     *qn = (size_t)B * H * Lq * Dp; *kn = (size_t)B * H * Lk * Dp; *vn = (size_t)B * H * Dm * Lkp;
     return *qn + *kn + *vn;
 }
