@@ -39,16 +39,18 @@ namespace td {
 
 struct AttnStrides { long b, h, t, c; };  // element strides of (batch, head, token, channel)
 
-// Round 6, "folded softmax bookkeeping" (head dims <= 80: the terrain U-Net's 64, SD-v1.5's 40 / 80).  Two of the three per-score VALU passes of the online softmax move
-// to the matrix pipe, which idles 70 % of the time at these head dims:
-//   * the subtraction of the reference point m rides in ONE EXTRA CHANNEL of the Q K^T contraction: K carries 1.0 there, Q carries -m (bf16; m is kept bf16-
+// Round 6, "folded softmax bookkeeping" -- for head dims that are NOT a multiple of 16 (SD-v1.5's 40; 8, 24, ...), whose operands carry padding anyway.  Two of the
+// three per-score VALU passes of the online softmax move to the matrix pipe, which idles 70 % of the time at these head dims:
+//   * the subtraction of the reference point m rides in ONE PADDING CHANNEL of the Q K^T contraction: K carries 1.0 there, Q carries -m (bf16; m is kept bf16-
 //     representable, so numerator and denominator see exactly the same reference) -- the MFMA delivers s - m;
-//   * the row sum l rides in ONE EXTRA ROW of V^T (1.0 for real keys): that row of O^T accumulates the sum of the bf16-rounded probabilities -- the values the
+//   * the row sum l rides in ONE PADDING ROW of V^T (1.0 for real keys): that row of O^T accumulates the sum of the bf16-rounded probabilities -- the values the
 //     numerator contracts, so the two are consistent by construction (the fp32 sum of round 3's "lean softmax" was not).
-// d = 40 has the room in its padding (48 contraction channels, 64 V^T rows); d = 64 / 80 pay one more k-step of Q K^T and one more 32-row block of V^T P^T.
-static inline bool attn_fold(int D) { return D <= 80; }
-static inline int attn_dp(int D) { return attn_fold(D) ? (D + 16) / 16 * 16 : (D + 15) / 16 * 16; }
-static inline int attn_dm(int D) { return attn_fold(D) ? (D + 32) / 32 * 32 : (D + 31) / 32 * 32; }
+// SD's 4096 x 4096 d = 40 problem: 91.4 -> 76.4 us, MFMA busy 28.5 -> 33.1 % (profiles/r06_attention_folded_softmax.txt).  Where the channel / row has to be PAID for
+// (d = 64: one more k-step of Q K^T, one more 32-row block of V^T P^T = 22 instead of 16 MFMAs per 64-key tile, wider K / V^T tiles through LDS) the same kernel is
+// 6 - 12 % SLOWER at 38 % MFMA busy -- measured, not shipped: a multiple of 16 keeps the plain form.
+static inline bool attn_fold(int D) { return (D & 15) != 0; }
+static inline int attn_dp(int D) { return (D + 15) / 16 * 16; }
+static inline int attn_dm(int D) { return (D + 31) / 32 * 32; }
 
 // grid (ceil(L / 64), H, B) x 3 roles via blockIdx.x ranges is overkill: one launch per operand (which = 0 q, 1 k, 2 v)
 template <typename TIN>
@@ -111,18 +113,12 @@ __global__ __launch_bounds__(256) void attn_pack_qkv64_kernel(const TIN* __restr
     }
     inv[0] *= qscale; inv[1] *= 1.f; inv[2] *= 1.f;
     const long bh = (long)b * H + h;
-    constexpr int Dp = 80, Dm = 96;   // attn_dp(64), attn_dm(64): one extra contraction channel (K: 1.0, Q: the reference point, 0 at the start), one extra V^T row (1.0 for real keys)
     if (real) {
-        Qp[(bh * L + tok) * Dp + lane] = (__bf16)(x[0] * inv[0]);
-        Kp[(bh * L + tok) * Dp + lane] = (__bf16)(x[1] * inv[1]);
-        if (lane < Dp - 64) {
-            Qp[(bh * L + tok) * Dp + 64 + lane] = (__bf16)0.f;
-            Kp[(bh * L + tok) * Dp + 64 + lane] = lane == 0 ? (__bf16)1.f : (__bf16)0.f;
-        }
+        Qp[(bh * L + tok) * 64 + lane] = (__bf16)(x[0] * inv[0]);
+        Kp[(bh * L + tok) * 64 + lane] = (__bf16)(x[1] * inv[1]);
     }
     const int pk = (tok & ~15) | (tok & 3) | (((tok >> 3) & 1) << 2) | (((tok >> 2) & 1) << 3);  // key order inside a group of 16 (see header)
-    Vt[(bh * Dm + lane) * Lkp + pk] = (__bf16)(x[2] * inv[2]);   // padded keys: zeros
-    if (lane < Dm - 64) Vt[(bh * Dm + 64 + lane) * Lkp + pk] = (lane == 0 && real) ? (__bf16)1.f : (__bf16)0.f;
+    Vt[(bh * 64 + lane) * Lkp + pk] = (__bf16)(x[2] * inv[2]);   // padded keys: zeros
 }
 
 #ifndef TD_ATTN_THR
@@ -424,9 +420,9 @@ static hipError_t attn_mfma(const __bf16* Qp, const __bf16* Kp, const __bf16* Vt
         if (big) hipLaunchKernelGGL((attn_mfma_kernel<A, M, 8, F>), grid, blk, 0, st, Qp, Kp, Vt, out_f32, out_b16, ost, Lq, Lk, Lkp, D);        \
         else hipLaunchKernelGGL((attn_mfma_kernel<A, M, 4, F>), grid, blk, 0, st, Qp, Kp, Vt, out_f32, out_b16, ost, Lq, Lk, Lkp, D);            \
         return hipGetLastError(); }
-    // head dims <= 80 (folded softmax bookkeeping: D + 1 contraction channels / V^T rows) ... 81 - 160 (plain)
-    TD_ATTN_CASE(1, 1, true) TD_ATTN_CASE(2, 1, true) TD_ATTN_CASE(3, 2, true) TD_ATTN_CASE(4, 2, true) TD_ATTN_CASE(5, 3, true) TD_ATTN_CASE(6, 3, true)
-    TD_ATTN_CASE(6, 3, false) TD_ATTN_CASE(7, 4, false) TD_ATTN_CASE(8, 4, false) TD_ATTN_CASE(9, 5, false) TD_ATTN_CASE(10, 5, false)
+    // (folded form for head dims with a padding channel / row, plain form for multiples of 16)
+    TD_ATTN_CASE(1, 1, true) TD_ATTN_CASE(2, 1, true) TD_ATTN_CASE(3, 2, true) TD_ATTN_CASE(4, 2, true) TD_ATTN_CASE(5, 3, true) TD_ATTN_CASE(6, 3, true) TD_ATTN_CASE(7, 4, true) TD_ATTN_CASE(8, 4, true) TD_ATTN_CASE(9, 5, true) TD_ATTN_CASE(10, 5, true)
+    TD_ATTN_CASE(1, 1, false) TD_ATTN_CASE(2, 1, false) TD_ATTN_CASE(3, 2, false) TD_ATTN_CASE(4, 2, false) TD_ATTN_CASE(5, 3, false) TD_ATTN_CASE(6, 3, false) TD_ATTN_CASE(7, 4, false) TD_ATTN_CASE(8, 4, false) TD_ATTN_CASE(9, 5, false) TD_ATTN_CASE(10, 5, false)
 #undef TD_ATTN_CASE
     return hipErrorInvalidValue;
 }

@@ -75,6 +75,31 @@ def test_attention_arbitrary_scale_long_keys_d40(scale):
     assert e32 < 1.5e-2 and e16 < 6e-3 and e16s < 4e-3
 
 
+@pytest.mark.parametrize("shift,spread", [(-300.0, 1.0), (250.0, 1.0), (0.0, 40.0)])
+def test_attention_folded_reference_point_moves_both_ways(shift, spread):
+    """Round 6: at head dims with padding (D % 16 != 0) the softmax's reference point rides in a padding channel of the Q K^T contraction and starts at 0
+    (csrc/attn_mfma.hip, attn_fold).  It has to move DOWN when every logit of a query lies far below it (shift -300: exp2 of the raw logits would underflow
+    to a zero row sum), UP when they lie far above (shift +250: overflow), and repeatedly when the maxima keep growing along the keys (spread 40: logits of
+    increasing magnitude; the in-register Q fragment is rewritten on each move).  Logits are shifted by adding a constant channel pair to q and k."""
+    from terrain_diffusion_amd.attention import attention
+    g = torch.Generator().manual_seed(606)
+    D, Lq, Lk = 40, 200, 700
+    q, k, v = (torch.randn(1, 2, L, D, generator=g) for L in (Lq, Lk, Lk))
+    scale = 1.0 / math.sqrt(D)
+    # channel 0: q = c, k = shift / (c * scale)  ->  every logit gets +shift (in natural-log units); bf16 rounds c and the quotient, the reference uses the rounded values
+    c = 4.0
+    q[..., 0] = c
+    k[..., 0] = shift / (c * scale)
+    k = k * torch.linspace(1.0, spread, Lk).view(1, 1, Lk, 1) if spread != 1.0 else k   # growing key norms: the running maximum keeps moving
+    out = attention(q, k, v, scale=scale).cpu()
+    assert torch.isfinite(out).all()
+    f = scale * 1.4426950408889634
+    rb = lambda t: t.bfloat16().float()
+    e = rel_rms(out.numpy(), _ref(rb(q * f) / f, rb(k), rb(v), scale, False).numpy())
+    print(f"folded softmax, logits shifted by {shift}, key spread {spread}: rel-RMS {e:.2e} vs the reference on the kernel's operands")
+    assert e < 6e-3
+
+
 def test_unet_attention_blocks_use_the_mfma_kernel_and_match():
     """the engine's own attention blocks (bf16 mode) go through the MFMA kernel; option attn_mfma=0 selects the scalar fp32 kernel of round 1:
     the two must agree to bf16 rounding, and 16x16-level attention (256 tokens) -- impossible for the scalar kernel -- runs."""

@@ -33,8 +33,7 @@ for idx, (name, B, H, Lq, Lk, D, norm) in enumerate(CASES):
     eng.synchronize()
     dt = (time.perf_counter() - t0) / reps
     useful = 4.0 * B * H * Lq * Lk * D
-    # (round 6: head dims <= 80 contract D + 1 channels / V^T rows -- the softmax's reference point and row sum ride on the matrix pipe, csrc/attn_mfma.hip attn_fold)
-    Dp, Dm = ((D + 16) // 16 * 16, (D + 32) // 32 * 32) if D <= 80 else ((D + 15) // 16 * 16, (D + 31) // 32 * 32)
+    Dp, Dm = (D + 15) // 16 * 16, (D + 31) // 32 * 32   # (round 6: where D % 16 != 0 one padding channel / V^T row carries the softmax's reference point / row sum)
     Lkp, Lqp = (Lk + 63) // 64 * 64, (Lq + 127) // 128 * 128
     issued = 2.0 * B * H * Lqp * Lkp * (Dp + Dm)
     print(f"CASE {idx} | {name} | B{B} H{H} {Lq}x{Lk} d{D} | useful GFLOP {useful / 1e9:.3f} | issued MFMA GFLOP {issued / 1e9:.3f} | wall per call (pack + kernel + sync) {dt * 1e6:.1f} us")
