@@ -266,7 +266,10 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
             moved = __builtin_amdgcn_ballot_w64(mt > (float)TD_ATTN_THR || m_run < -64.f) != 0;
             if (moved) {
                 const float m_new = (float)(__bf16)(m_ref + m_run), delta = m_new - m_ref;   // exact: both bf16 values
-                alpha = __builtin_amdgcn_exp2f(-delta);
+                // A reference can only fall by more than 2^64 in a query's FIRST tile (its running maximum never decreases, and after any move it sits at the
+                // reference): O and the row sum are still exactly 0 there, so the factor is clamped instead of overflowing to inf (0 x inf = NaN); everywhere else
+                // |delta| <= 64 + THR and the factor is exact.
+                alpha = __builtin_amdgcn_exp2f(fminf(-delta, 64.f));
                 m_ref = m_new; m_run -= delta;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
