@@ -7,7 +7,7 @@
 //   attn_pack_kernel  reads q, k, v through arbitrary element strides (the U-Net's interleaved NHWC qkv tensor, or plain [B][H][L][D]), applies
 //                     the optional per-token unit-RMS normalisation x / (1e-4 + ||x|| / sqrt(D)) (mp_layers.py:9-12, dim=2 of the
 //                     (N, heads, C, 3, HW) view), and writes bf16 operands in the shapes the MFMA kernel wants: Qp / Kp [B][H][L][Dp] (d padded to a
-//                     multiple of 16 with zeros) and V TRANSPOSED Vt [B][H][Dm][Lkp] (Dm = D rounded up to 32, keys padded to 128) with the 16 keys
+//                     multiple of 16 with zeros) and V TRANSPOSED Vt [B][H][Dm][Lkp] (Dm = D rounded up to 32, keys padded to 64) with the 16 keys
 //                     of every group stored in the order {0-3, 8-11, 4-7, 12-15} -- see below.
 //   attn_mfma_kernel  flash-style forward.  One wave owns 32 queries; a 4-wave workgroup shares 64-key K / Vt tiles staged in LDS.
 //     * S^T = K Q^T on v_mfma_f32_32x32x16_bf16 with K as the A operand (rows = keys) and Q as the B operand (columns = queries): a lane then holds
@@ -51,9 +51,6 @@ struct AttnStrides { long b, h, t, c; };  // element strides of (batch, head, to
 static inline bool attn_fold(int D) { return (D & 15) != 0; }
 static inline int attn_dp(int D) { return (D + 15) / 16 * 16; }
 static inline int attn_dm(int D) { return (D + 31) / 32 * 32; }
-// keys per staged K / V^T tile (= per workgroup barrier): 128 for head dims <= 96 (round 6: the barrier wait was 16 - 19 % of a 64-key tile), 64 above (LDS, staging registers);
-// V^T rows are padded to a multiple of 128 keys either way
-static inline int attn_lkp(int Lk) { return (Lk + 127) / 128 * 128; }
 
 // grid (ceil(L / 64), H, B) x 3 roles via blockIdx.x ranges is overkill: one launch per operand (which = 0 q, 1 k, 2 v)
 template <typename TIN>
@@ -137,9 +134,9 @@ __global__ __launch_bounds__(256) void attn_pack_qkv64_kernel(const TIN* __restr
 template <int DP16, int DM32, int NW, bool FOLD>
 __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __restrict__ Qp, const __bf16* __restrict__ Kp, const __bf16* __restrict__ Vt, float* __restrict__ out_f32,
                                                         __bf16* __restrict__ out_b16, AttnStrides ost, int Lq, int Lk, int Lkp, int D) {
-    constexpr int Dp = DP16 * 16, Dm = DM32 * 32, TK = DM32 <= 3 ? 128 : 64;   // keys per staged tile / barrier; the softmax works in 64-key halves
+    constexpr int Dp = DP16 * 16, Dm = DM32 * 32, TK = 64;
     constexpr int KSL = (Dp / 8) | 1, KPITCH = KSL * 16;      // K rows: odd number of 16-byte slots
-    constexpr int VPITCH = (TK / 8 + 1) * 16;                 // Vt rows: 64 keys = 8 slots -> 9 (128 keys: 17)
+    constexpr int VPITCH = (TK / 8 + 1) * 16;                 // Vt rows: 64 keys = 8 slots -> 9
     // K / V^T tiles are DOUBLE-buffered in LDS (round 3): tile t+1 travels global -> registers while tile t-1 is computed and is written to the
     // other buffer at the top of tile t, so a tile costs one workgroup barrier instead of two
     __shared__ __attribute__((aligned(16))) unsigned char s_k[2][TK * KPITCH];
@@ -181,7 +178,7 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
 #pragma unroll
         for (int it = 0; it < VIT; ++it) {
             const int e0 = tid + it * NTHR, e = e0 < VPIECES ? e0 : VPIECES - 1, r = e / (TK / 8), sl = e % (TK / 8);
-            vreg[it] = *(const u32x4*)(vbase + (long)r * Lkp + k0 + sl * 8);   // Lkp is a multiple of 128, padding keys are zero
+            vreg[it] = *(const u32x4*)(vbase + (long)r * Lkp + k0 + sl * 8);   // Lkp is a multiple of 64, padding keys are zero
         }
     };
     auto store_tile = [&](int buf) {
@@ -215,13 +212,9 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
         store_tile(buf ^ 1);
         TD_AT(4)
         { const int k2 = k0 + 2 * TK; load_tile(k2 < Lk ? k2 : (nt_ - 1) * TK); }
+        const unsigned char* sk_ = s_k[buf];
+        const unsigned char* sv_ = s_v[buf];
         TD_AT(0)
-#pragma unroll
-        for (int hk = 0; hk < TK / 64; ++hk) {   // 64-key halves of the staged tile
-        if (hk > 0 && k0 + hk * 64 >= Lk) break;   // (wave-uniform: the ragged last tile may end in its first half)
-        const unsigned char* sk_ = s_k[buf] + hk * 64 * KPITCH;
-        const unsigned char* sv_ = s_v[buf] + hk * 128;   // 64 keys = eight 16-byte slots of every V^T row
-        const int kh0 = k0 + hk * 64;
         // ---- S^T = K Q^T for two 32-key blocks
         f32x16 s[2];
 #pragma unroll
@@ -246,12 +239,12 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
         // in round 2), so it is kept lean: no scaling multiply (folded into Q), the key mask only on the last, ragged tile, three-input
         // maxima, one v_cvt_pk per two probabilities -- and, FOLD (round 6), neither the subtraction of the reference point nor the row sum
         // (both on the matrix pipe: attn_fold).
-        if (kh0 + 64 > Lk) {  // wave-uniform: only the last half tile of a ragged key length
+        if (k0 + TK > Lk) {  // wave-uniform: only the last tile of a ragged key length
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = kh0 + kb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+                    const int key = k0 + kb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
                     if (key >= Lk) s[kb][r] = -3.0e38f;
                 }
         }
@@ -358,7 +351,6 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
         asm volatile("s_nop 0" :: "v"(o[0][0]), "v"(o[DM32 - 1][0]));
 #endif
         TD_AT(3)
-        }
         __syncthreads();
     }
 #ifdef TD_ATTN_TRACE
@@ -405,7 +397,7 @@ template <typename TIN>
 static hipError_t attn_pack(const TIN* q, const TIN* k, const TIN* v, AttnStrides sq, AttnStrides sk, AttnStrides sv, int B, int H, int Lq, int Lk, int D, int normalize,
                             float scale, __bf16* Qp, __bf16* Kp, __bf16* Vt, hipStream_t st) {
     const float qscale = scale * 1.4426950408889634f;  // folded into Q (see attn_pack_kernel)
-    const int Dp = attn_dp(D), Dm = attn_dm(D), Lkp = attn_lkp(Lk), fold = attn_fold(D) ? 1 : 0;
+    const int Dp = attn_dp(D), Dm = attn_dm(D), Lkp = (Lk + 63) / 64 * 64, fold = attn_fold(D) ? 1 : 0;
     hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lq + 3) / 4, H, B), dim3(256), 0, st, q, sq, Lq, D, Dp, Dm, Lkp, 0, normalize, qscale, Qp, fold);
     hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lk + 3) / 4, H, B), dim3(256), 0, st, k, sk, Lk, D, Dp, Dm, Lkp, 1, normalize, 1.f, Kp, fold);
     hipLaunchKernelGGL(attn_pack_kernel<TIN>, dim3((Lkp + 3) / 4, H, B), dim3(256), 0, st, v, sv, Lk, D, Dp, Dm, Lkp, 2, normalize, 1.f, Vt, fold);
@@ -414,14 +406,14 @@ static hipError_t attn_pack(const TIN* q, const TIN* k, const TIN* v, AttnStride
 
 template <typename TIN>
 static hipError_t attn_pack_qkv64(const TIN* qkv, long tok_stride, int B, int H, int L, float scale, __bf16* Qp, __bf16* Kp, __bf16* Vt, hipStream_t st) {
-    const int Lkp = attn_lkp(L);
+    const int Lkp = (L + 63) / 64 * 64;
     hipLaunchKernelGGL(attn_pack_qkv64_kernel<TIN>, dim3((Lkp + 3) / 4, H, B), dim3(256), 0, st, qkv, L, Lkp, tok_stride, scale * 1.4426950408889634f, Qp, Kp, Vt);
     return hipGetLastError();
 }
 
 static hipError_t attn_mfma(const __bf16* Qp, const __bf16* Kp, const __bf16* Vt, float* out_f32, __bf16* out_b16, AttnStrides ost, int B, int H, int Lq, int Lk, int D,
                             hipStream_t st) {
-    const int Dp16 = attn_dp(D) / 16, Dm32 = attn_dm(D) / 32, Lkp = attn_lkp(Lk);
+    const int Dp16 = attn_dp(D) / 16, Dm32 = attn_dm(D) / 32, Lkp = (Lk + 63) / 64 * 64;
     const bool fold = attn_fold(D);
     // 8 waves (256 queries) per workgroup when there are enough queries to fill the chip that way: the K / V^T tile is staged once per workgroup
     static const long big_min = getenv("TD_ATTN_BIG_MIN") ? atol(getenv("TD_ATTN_BIG_MIN")) : 256;   // A/B hook (tools/attn_bench.py)
@@ -439,7 +431,7 @@ static hipError_t attn_mfma(const __bf16* Qp, const __bf16* Kp, const __bf16* Vt
 }
 
 static size_t attn_workspace_elems(int B, int H, int Lq, int Lk, int D, size_t* qn, size_t* kn, size_t* vn) {
-    const size_t Dp = attn_dp(D), Dm = attn_dm(D), Lkp = attn_lkp(Lk);
+    const size_t Dp = attn_dp(D), Dm = attn_dm(D), Lkp = (Lk + 63) / 64 * 64;
     *qn = (size_t)B * H * Lq * Dp; *kn = (size_t)B * H * Lk * Dp; *vn = (size_t)B * H * Dm * Lkp;
     return *qn + *kn + *vn;
 }

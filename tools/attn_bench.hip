@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     const double useful = 4.0 * B * H * Lq * Lk * D;
-    const int Dp = attn_dp(D), Dm = attn_dm(D), Lkp = (Lk + 63) / 64 * 64 /* issued MFMA work: whole 64-key halves */, Lqp = (Lq + 255) / 256 * 256;   // (round 6: where D % 16 != 0 a padding channel / row carries the softmax's reference point / row sum, attn_fold)
+    const int Dp = attn_dp(D), Dm = attn_dm(D), Lkp = (Lk + 63) / 64 * 64, Lqp = (Lq + 255) / 256 * 256;   // (round 6: where D % 16 != 0 a padding channel / row carries the softmax's reference point / row sum, attn_fold)
     const double issued = 2.0 * B * H * Lqp * Lkp * (Dp + Dm);
     printf("B%d H%d %dx%d d%d : %.1f us  useful %.1f TFLOP/s  issued-MFMA %.1f TFLOP/s (%.1f %% of 2500)\n", B, H, Lq, Lk, D, ms * 1e3, useful / ms / 1e9, issued / ms / 1e9, issued / ms / 1e9 / 25.0);
     std::vector<float> ho(nq);
