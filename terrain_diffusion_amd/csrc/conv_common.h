@@ -241,6 +241,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                          \
                  ::"v"(VOFF), "s"(SBASE), "s"(LDS_BASE), "n"(IMM) : "memory", "scc")
 
+// one dword per lane, global -> LDS[m0 base + 4 * lane]
+#define TD_GLDS4(VOFF, SBASE, LDS_BASE, IMM)                                                                  \
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"                            \
+                 ::"v"(VOFF), "s"(SBASE), "s"(LDS_BASE), "n"(IMM) : "memory", "scc")
+
+// a wave-uniform pointer the compiler holds in vector registers, as an SGPR pair (operand of an inline-asm "s" constraint)
+// (s_nop 4: an SGPR written by the VALU -- v_readfirstlane -- needs five wait states before a VMEM instruction reads it; the compiler's hazard recogniser
+// does not look inside inline asm, and the first build's patch loads went out with a stale upper address half: memory fault)
+template <typename P> __device__ __forceinline__ const P* td_uniform_ptr(const P* q) {
+    const unsigned long long a = (unsigned long long)q;
+    int lo = __builtin_amdgcn_readfirstlane((int)a), hi = __builtin_amdgcn_readfirstlane((int)(a >> 32));
+    asm volatile("s_nop 4" : "+s"(lo), "+s"(hi));
+    return (const P*)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
 // exact a / d for a < 2^32 / d with M = ceil(2^32 / d) (host: td_magic); d == 1 has no 32-bit M.  The workgroup-id decomposition of the conv
 // kernels: a run-time integer division is ~40 scalar + vector instructions (v_rcp_iflag_f32 + corrections), and a kernel prologue had six of them
 __device__ __forceinline__ unsigned td_udiv(unsigned a, unsigned d, unsigned M) { return d == 1 ? a : __umulhi(a, M); }

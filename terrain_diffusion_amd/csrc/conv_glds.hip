@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, TD_GLDS_MIN_WAVES(BN, WAVES
             }
 #define TD_P_PREP(BUF)                                                                                                \
                 const unsigned long long sa_ = (unsigned long long)(psrc + (size_t)pchunk * CHUNK);                   \
-                const unsigned char* su_ = (const unsigned char*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sa_ >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)sa_)); \
+                const unsigned char* su_ = td_uniform_ptr((const unsigned char*)sa_); \
                 const unsigned lb_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(ldsw + (unsigned)A_BASE + (unsigned)(BUF) * (unsigned)STAGE_BYTES));
 #define TD_P_PIECES(I0, I1)                                                                                           \
                 _Pragma("unroll") for (int i_ = (I0); i_ < (I1); ++i_) TD_GLDS16(poff[i_], su_, lb_, i_ * NTHR * 16);

@@ -674,7 +674,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
     static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn",
                                                "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
                                                "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups", "glds_round_aware", "walk_alternate", "glds_tiny", "glds_dma1x1", "splitk_weighted",
-                                               "sb", "sb_target_wgs", "sb_mt", "sb_nt", "sb_order", "sb_max_glds_wgs", "sb_splitk", "sb_splitk_wgs", "sb_splitk_max", "s16", "s16_min_wgs", "sb_m4", "glds_wide", "glds_wide_min_wgs", "glds_wide_tail"};
+                                               "sb", "sb_target_wgs", "sb_mt", "sb_nt", "sb_order", "sb_max_glds_wgs", "sb_splitk", "sb_splitk_wgs", "sb_splitk_max", "s16", "s16_min_wgs", "sb_m4", "glds_wide", "glds_wide_min_wgs", "glds_wide_tail", "glds_wide_persist"};
     std::string key = std::to_string(N) + "_" + std::to_string(H) + "_" + std::to_string(W);
     for (const char* o : kPlanOptions) key += "_" + std::to_string((long long)u->eng->option(o, -7));
     if (lane) key += "_lane" + std::to_string(lane);   // a second, independent activation set of the same shape (concurrent half-batches)
@@ -841,6 +841,14 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
                         (wmode == 2 || wgs_w >= u->eng->option("glds_wide_min_wgs", 384))) {
                         op.glds_variant = 3; op.bn = bnw;
                         p.tiles_x = (w + 15) / 16; p.tiles_y = (h + 15) / 16; p.img_groups = N; p.n_ntiles = cw.cout_pad / bnw;
+                        // Persistent tile loop of the wide tile (option "glds_wide_persist", default 0): 2 x CUs workgroups walk the launch's tiles, the next tile's first
+                        // patch, modulation row and weight half tiles requested under the current tile's taps, staging split by wave (two waves stream weights, two stage
+                        // patches).  Exists for the 64-cout tile, pure 3x3 launches over whole 16 x 16 tiles.  Bit-identical to the one-tile-per-workgroup form and,
+                        // measured, not faster (profiles/r06_wide_tile_persistent_loop.txt) -- which is why it is off.
+                        bool tail3 = false;
+                        for (const SegSpec& sg : segs) if (sg.taps != 9) tail3 = true;
+                        if (u->eng->option("glds_wide_persist", 0) != 0 && bnw == 64 && !tail3 && (h & 15) == 0 && (w & 15) == 0 && cw.cout == cw.cout_pad)
+                            p.persist = conv_wide_persist_grid((long long)p.tiles_x * p.tiles_y * N * p.n_ntiles, 2 * std::max(1, u->eng->n_cus));
                     }
                 }
                 // Small-batch flavour (conv_sb.hip, round 4) wherever the throughput tiles do not fill the chip (workgroups x 2 <= CU slots: the
@@ -1202,7 +1210,7 @@ static int run_unet(td_unet* u, Plan& pl, int step, const SchedCoef* fuse = null
             const double mbs_ = (mb_ + o1_) * 1e-6;   /* strict: without the optional pre-activated second output (an optimisation, not part of the layer's definition) */
             mb_ += o1_ * (p.out2 ? 2.0 : 1.0);
             mb_ *= 1e-6;
-            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f mb%.2f mbs%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 5 ? "c16" : op.flavor == 4 ? (op.sb_mt == 4 ? "m4n1" : op.sb_mt == 2 ? (op.sb_nt == 2 ? "m2n2" : "m2n1") : (op.sb_nt == 2 ? "m1n2" : "m1n1")) : op.flavor == 2 ? (op.glds_variant == 3 ? "w" : op.glds_variant == 2 ? "t" : op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_, mb_, mbs_); ev_label.push_back(op.label + tag);
+            snprintf(tag, sizeof tag, " [%dx%d k%d f%d%s bn%d wg%d ks%d gf%.2f mb%.2f mbs%.2f]", p.H, p.W, p.kgroups, op.flavor, op.flavor == 5 ? "c16" : op.flavor == 4 ? (op.sb_mt == 4 ? "m4n1" : op.sb_mt == 2 ? (op.sb_nt == 2 ? "m2n2" : "m2n1") : (op.sb_nt == 2 ? "m1n2" : "m1n1")) : op.flavor == 2 ? (op.glds_variant == 3 ? (p.persist > 0 ? "wp" : "w") : op.glds_variant == 2 ? "t" : op.glds_variant ? "s" : "b") : "", op.bn, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, p.ksplit, gf_, mb_, mbs_); ev_label.push_back(op.label + tag);
             ev_flop.push_back(op.flavor == 2 ? 2.0 * p.N * p.H * p.W * (double)p.Cout * op.k_alg : 0.0); }   // the LDS-DMA family alone (bench.py's roofline kernel); small-batch launches are told apart by their f4 label
         if (e != hipSuccess) return fail(TD_ERR_HIP, "conv launch " + op.label + ": " + hipGetErrorString(e));
     }
@@ -1273,7 +1281,7 @@ static const char* const kKnownOptions[] = {
     "plan_cache_mb", "plan_cache_max",
     // plan builder (speed only, or test hooks that force a tile shape; all part of the plan-cache key)
     "attn_mfma", "bn128_min_wgs", "glds", "glds_bn", "glds_bn64", "glds_dma1x1", "glds_min_wgs", "glds_round_aware", "glds_small_max_groups",
-    "glds_splitk", "glds_splitk_from_groups", "glds_splitk_max", "glds_splitk_min_groups", "glds_tiny", "glds_variant", "glds_wide", "glds_wide_min_wgs", "glds_wide_tail",
+    "glds_splitk", "glds_splitk_from_groups", "glds_splitk_max", "glds_splitk_min_groups", "glds_tiny", "glds_variant", "glds_wide", "glds_wide_min_wgs", "glds_wide_tail", "glds_wide_persist",
     "producer_act", "s16", "s16_min_wgs", "sb", "sb_m4", "sb_max_glds_wgs", "sb_mt", "sb_nt", "sb_order", "sb_splitk", "sb_splitk_max", "sb_splitk_wgs", "sb_target_wgs", "splitk",
     "splitk_target_wgs", "splitk_weighted", "walk_alternate"};
 int td_engine_set_option(td_engine* e, const char* key, int64_t value) {

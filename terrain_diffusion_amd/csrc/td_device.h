@@ -86,6 +86,7 @@ struct ConvParams {
     int reverse;          // scheduling hint (speed only, never changes a bit): 1 = logical workgroup ids are walked backwards (the host alternates it
                           // from layer to layer: the producer's last-written, still cached rows are read first)
     int dma1x1;           // conv_glds: stream 1x1 segments by LDS-DMA when the launch qualifies (launch_glds_cfg decides)
+    int persist;          // conv_glds_wide.hip: > 0 = persistent tile loop with this many workgroups (the stride of a workgroup's tile walk); 0 = one tile per workgroup
     // conv_sb.hip (small-batch flavour): the same weights in MFMA-fragment order [K-group][16-channel slice][tap][32-cout tile][lane][16 B]
     const void* wpack_sb;
     int sb_n3;            // number of leading 3x3 K-groups (every 3x3 segment precedes every 1x1 segment)

@@ -133,6 +133,36 @@ def test_conv_tile_variants_bit_identical(td, base, n):
         assert torch.equal(y, y0), (k, float((y - y0).abs().max()))
 
 
+def test_wide_tile_persistent_loop_same_bits(td):
+    """Round 6: the wide tile's persistent tile loop (engine option glds_wide_persist = 1; conv_glds_wide.hip, PERS instantiation: 2 x CUs workgroups walk the
+    launch's tiles, staging split by wave) keeps the K order of the one-tile-per-workgroup form: the decoder model's forward at 256 x 256 (its 64-channel
+    256 x 256 level is 1024 tiles per launch at batch 4 = two rounds of 512 workgroups; encoder blocks with pixel-norm factors, modulation rows, residual
+    runs, second outputs and sum-of-squares planes) must come out bit for bit the same with the loop on and off."""
+    from oracle.unet import DECODER_CONFIG, synth_state_dict
+    from terrain_diffusion_amd.engine import get_engine
+    from oracle import rng
+    eng = get_engine("cuda")
+    m = td.EDMUnet2D(**DECODER_CONFIG, dtype="bf16").load_state_dict(synth_state_dict(DECODER_CONFIG, seed=97))
+    x = torch.from_numpy(rng.standard_normal(5, (4, DECODER_CONFIG["in_channels"], 256, 256))).cuda()
+    t = torch.full((4,), 0.9)
+    outs, tags = {}, {}
+    try:
+        for v in (0, 1):
+            eng.set_option("glds_wide_persist", v)
+            eng.set_option("profile", 1); eng.profile_read(reset=True)
+            outs[v] = m(x, t, []).clone()
+            tags[v] = [l for l, _, _ in eng.profile_ops()]
+            eng.profile_read(reset=True)
+    finally:
+        eng.set_option("profile", 0); eng.set_option("glds_wide_persist", 0)
+    n_p = sum(" f2wp " in l for l in tags[1])
+    print("launches on the persistent loop:", n_p, "of", sum(" f2w" in l for l in tags[1]), "wide launches")
+    assert n_p >= 4 and all(" f2wp " not in l for l in tags[0]), (n_p, tags[1])
+    assert torch.isfinite(outs[0]).all() and float(outs[0].abs().mean()) > 1e-4
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    m.close()
+
+
 @pytest.mark.parametrize("n,hw", [(64, 64), (5, 72)])
 def test_wide_tile_against_the_other_tiles_and_the_oracle(td, base, n, hw):
     """Round 6: the wide tile of the LDS-DMA conv (conv_glds_wide.hip: 256 px x 96 / 64 couts, 4 waves, 32-channel K-groups, double-buffered patch).  Its K

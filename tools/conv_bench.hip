@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <string>
 #include <algorithm>
 #include <array>
 #ifdef TD_BENCH_EXTERN   // kernels linked from separately compiled objects (tools/build_bench.sh: the conv_glds family takes minutes to compile, the flavour under work seconds)
@@ -66,9 +67,11 @@ int main(int argc, char** argv) {
         p.nseg = 2; p.seg[1].src = x2; p.seg[1].C = Cin2; p.seg[1].cstride = Cin2; p.seg[1].Hs = H; p.seg[1].Ws = W; p.seg[1].taps = taps2; p.seg[1].xform = 0; p.seg[1].scale = 1.f;
     }
     p.dma1x1 = getenv("TD_DMA1X1") ? atoi(getenv("TD_DMA1X1")) : 1;
-    bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4) ? 4 : 2) : 1; int TH = flavor == 8 ? 4 : ((flavor == 2 || flavor == 4 || flavor == 9) && !narrow) ? 16 : 8;  // flavor 8 = conv_glds variant 2 (tiny tile); 9 = conv_glds_wide.hip (256 px x bn, 4 waves, two workgroups per CU)
+    bool narrow = W < 16; int TW = narrow ? 8 : 16, NIMG = narrow ? ((flavor == 2 || flavor == 4) ? 4 : 2) : 1; const bool pers = flavor == 10; if (pers) flavor = 9;   /* 10 = the wide tile's persistent tile loop (p.persist workgroups; TD_PERSIST=G overrides 2 x 256 slots' rule) */ int TH = flavor == 8 ? 4 : ((flavor == 2 || flavor == 4 || flavor == 9) && !narrow) ? 16 : 8;  // flavor 8 = conv_glds variant 2 (tiny tile); 9 = conv_glds_wide.hip (256 px x bn, 4 waves, two workgroups per CU)
     p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH; p.img_groups = (N + NIMG - 1) / NIMG; p.n_ntiles = Cout / bn;
     p.epi = epi; p.out = out; p.out_cstride = Cout;
+    if (pers) { const long long tiles = (long long)p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups, slots = 512, rounds = (tiles + slots - 1) / slots; long long g = (tiles + rounds - 1) / rounds; if ((tiles & 7) == 0) g = (g + 7) & ~7LL;
+        p.persist = getenv("TD_PERSIST") ? atoi(getenv("TD_PERSIST")) : (int)std::min(g, tiles); }
     { void* z; CK(hipMalloc(&z, 4096)); CK(hipMemset(z, 0, 4096)); p.zeros = z; }
     if (epi == EPI_EMB_SILU) { float* cv; CK(hipMalloc(&cv, (size_t)N * Cout * 4)); std::vector<float> hc((size_t)N * Cout); for (size_t i_ = 0; i_ < hc.size(); ++i_) hc[i_] = 0.75f + 0.001f * (float)(i_ % 509);   /* varied: an indexing slip in the kernel's modulation-row staging must change bits */ CK(hipMemcpy(cv, hc.data(), hc.size() * 4, hipMemcpyHostToDevice)); p.cvec = cv; p.cvec_stride = Cout; }
     if (epi == EPI_RESIDUAL) { void* r; float* ssq; CK(hipMalloc(&r, M * Cout * 2)); CK(hipMemcpy(r, hx.data(), std::min(hx.size(), M * Cout) * 2, hipMemcpyHostToDevice)); CK(hipMalloc(&ssq, M * (Cout / 32 + 8) * 4)); CK(hipMemset(ssq, 0, M * (Cout / 32 + 8) * 4));
@@ -108,8 +111,30 @@ int main(int argc, char** argv) {
             fclose(fp); }
     }
     double flop = 2.0 * M * Cout * ((double)Cin * taps + (double)Cin2 * taps2);
-    printf("N%d %dx%d Cin%d Cout%d taps%d xform%d bn%d ks%d fl%d epi%d stg%d ch%d : %.1f us  %.1f TFLOP/s (%.1f%% of 2500)  wgs=%d\n", N, H, W, Cin, Cout, taps, xform, bn, ksplit, flavor, epi, stagger, chain, ms * 1e3,
-           flop / ms / 1e9, flop / ms / 1e9 / 25.0, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * ksplit);
+    printf("N%d %dx%d Cin%d Cout%d taps%d xform%d bn%d ks%d fl%d epi%d stg%d ch%d : %.1f us  %.1f TFLOP/s (%.1f%% of 2500)  wgs=%d%s\n", N, H, W, Cin, Cout, taps, xform, bn, ksplit, pers ? 10 : flavor, epi, stagger, chain, ms * 1e3,
+           flop / ms / 1e9, flop / ms / 1e9 / 25.0, p.n_ntiles * p.tiles_x * p.tiles_y * p.img_groups * ksplit, pers ? (" persistent on " + std::to_string(p.persist)).c_str() : "");
+    if (pers && !getenv("TD_NO_CMP")) {   // the persistent tile loop against one tile per workgroup: same K order -> out, second output and sum-of-squares planes bit for bit
+        std::vector<uint16_t> o[2], o2[2]; std::vector<float> ss[2];
+        for (int d = 0; d < 2; ++d) {
+            ConvParams q = p; if (d == 0) q.persist = 0;
+            CK(hipMemset(out, 0, M * Cout * 2)); if (p.out2) CK(hipMemset(p.out2, 0, M * Cout * 2)); if (p.out_sumsq) CK(hipMemset(p.out_sumsq, 0, M * (Cout / 32) * 4));
+            CK(L(q)); CK(hipStreamSynchronize(st));
+            o[d].resize(M * Cout); CK(hipMemcpy(o[d].data(), out, M * Cout * 2, hipMemcpyDeviceToHost));
+            if (p.out2) { o2[d].resize(M * Cout); CK(hipMemcpy(o2[d].data(), p.out2, M * Cout * 2, hipMemcpyDeviceToHost)); }
+            if (p.out_sumsq) { ss[d].resize(M * (Cout / 32)); CK(hipMemcpy(ss[d].data(), p.out_sumsq, ss[d].size() * 4, hipMemcpyDeviceToHost)); }
+        }
+        size_t bad = 0, bad2 = 0, bads = 0, nz = 0;
+        for (size_t i = 0; i < o[0].size(); ++i) { bad += o[0][i] != o[1][i]; nz += (o[1][i] & 0x7fff) != 0; }
+        for (size_t i = 0; i < o2[0].size(); ++i) bad2 += o2[0][i] != o2[1][i];
+        for (size_t i = 0; i < ss[0].size(); ++i) bads += memcmp(&ss[0][i], &ss[1][i], 4) != 0;
+        if (bad && getenv("TD_DBG")) { size_t shown = 0; std::vector<size_t> hy(16, 0), hx(16, 0), hc(4, 0), ht(64, 0);
+            for (size_t i = 0; i < o[0].size(); ++i) if (o[0][i] != o[1][i]) { const size_t pix = i / Cout; const int c = (int)(i % Cout), x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((size_t)W * H));
+                hy[y & 15]++; hx[x & 15]++; hc[(c / 16) & 3]++; ht[((y >> 4) & 7) * 8 + ((x >> 4) & 7)]++;
+                if (shown++ < 12) printf("    n %d y %d x %d c %d: %04x vs %04x\n", n, y, x, c, o[0][i], o[1][i]); }
+            printf("    by y&15:"); for (auto v : hy) printf(" %zu", v); printf("\n    by x&15:"); for (auto v : hx) printf(" %zu", v); printf("\n    by (c/16)&3:"); for (auto v : hc) printf(" %zu", v);
+            printf("\n    by tile (ty&7, tx&7):"); for (auto v : ht) printf(" %zu", v); printf("\n"); }
+        printf("  check persistent vs one tile per workgroup: out %zu / %zu differ (nonzero %zu), out2 %zu / %zu, sumsq %zu / %zu\n", bad, o[0].size(), nz, bad2, o2[0].size(), bads, ss[0].size());
+    }
     if (Cin2 && (flavor == 2 || flavor == 3 || flavor == 8)) {  // register-staged vs LDS-DMA 1x1 path of conv_glds: same K order, same MFMA -> same bits
         std::vector<uint16_t> o0(M * Cout), o1(M * Cout);
         for (int d = 0; d < 2; ++d) {

@@ -37,5 +37,5 @@ tot = sum(r[1] for r in rows) / reps
 base_hw = 512 if which == "decoder" else 64
 gf = GFLOP[which] * n * (H / base_hw) ** 2
 print(f"{which} batch {n} {H}x{H} {dtype}: {tot:.3f} ms kernel time per forward, {gf / tot:.1f} TFLOP/s ({conv_n // reps} conv launches)")
-for r in sorted(rows, key=lambda r: -r[1])[:14]:
+for r in sorted(rows, key=lambda r: -r[1])[:int(os.environ.get("TD_TOP", "14"))]:
     print(f"{r[1] / reps * 1e3:9.1f} us  {r[0]}")
