@@ -93,6 +93,9 @@ int td_engine_set_stream(td_engine* e, void* hip_stream);
  *   "s16_min_wgs" workgroups / wherever conv_sb applies),
  *   "glds_wide"=0/1/2 (wide tile of the LDS-DMA flavour, conv_glds_wide.hip: never / pure-3x3 launches whose 256-pixel grid reaches "glds_wide_min_wgs"
  *   (384) workgroups / wherever it is legal), "glds_wide_tail"=0/1/2 (launches with an untransformed 1x1 tail on the wide tile: never / on its 64-cout tile (the decoder model) / always).
+ *   "glds_wide_persist"=0/1 (persistent tile loop of the wide tile's 64-cout instantiation, staging split by wave: same bits, measured slower -- default 0),
+ *   "fewcout"=1/0 (fp32-output 3x3 convs with <= 4 real output channels on maps >= 128 x 128 -- the decoder model's output conv -- on the VALU flavour
+ *   conv_fewcout.hip instead of a 64-cout MFMA tile).
  * Test hooks that force a tile shape wherever it is legal: "glds_variant"=-1/0/1, "glds_bn"=0/64/96/128, "sb_mt"=0/1/2/4, "sb_nt"=0/1/2. */
 int td_engine_set_option(td_engine* e, const char* key, int64_t value);
 

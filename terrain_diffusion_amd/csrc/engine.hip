@@ -20,6 +20,7 @@
 #include "conv_glds_wide.hip"
 #include "conv_sb.hip"
 #include "conv_s16.hip"
+#include "conv_fewcout.hip"
 #include "small_kernels.hip"
 #include "compose_kernels.hip"
 #include "attn_mfma.hip"
@@ -674,7 +675,7 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
     static const char* const kPlanOptions[] = {"batch_invariant", "glds", "splitk", "producer_act", "glds_min_wgs", "glds_variant", "glds_bn",
                                                "glds_splitk", "glds_splitk_max", "glds_splitk_min_groups", "splitk_target_wgs",
                                                "bn128_min_wgs", "attn_mfma", "glds_splitk_from_groups", "glds_bn64", "glds_small_max_groups", "glds_round_aware", "walk_alternate", "glds_tiny", "glds_dma1x1", "splitk_weighted",
-                                               "sb", "sb_target_wgs", "sb_mt", "sb_nt", "sb_order", "sb_max_glds_wgs", "sb_splitk", "sb_splitk_wgs", "sb_splitk_max", "s16", "s16_min_wgs", "sb_m4", "glds_wide", "glds_wide_min_wgs", "glds_wide_tail", "glds_wide_persist"};
+                                               "sb", "sb_target_wgs", "sb_mt", "sb_nt", "sb_order", "sb_max_glds_wgs", "sb_splitk", "sb_splitk_wgs", "sb_splitk_max", "s16", "s16_min_wgs", "sb_m4", "glds_wide", "glds_wide_min_wgs", "glds_wide_tail", "glds_wide_persist", "fewcout"};
     std::string key = std::to_string(N) + "_" + std::to_string(H) + "_" + std::to_string(W);
     for (const char* o : kPlanOptions) key += "_" + std::to_string((long long)u->eng->option(o, -7));
     if (lane) key += "_lane" + std::to_string(lane);   // a second, independent activation set of the same shape (concurrent half-batches)
@@ -931,6 +932,15 @@ static int build_plan(td_unet* u, int N, int H, int W, Plan** out, int lane = 0)
             const int64_t base = mt * p.n_ntiles;
             p.ksplit = 1;
             if (use_splitk && !u->eng->option("batch_invariant", 0) && base < splitk_target / 2 && kgroups > 1) p.ksplit = (int)std::min<int64_t>(kgroups, (splitk_target + base - 1) / base);
+        }
+        // Few-cout flavour (conv_fewcout.hip, round 6): an fp32-output 3x3 conv with <= 4 real couts (the decoder model's 64 -> 1 output conv) does its
+        // multiply-adds on the VALU, one pixel per thread, instead of a 64-cout MFMA tile for one cout.  Maps of >= 128 x 128 pixels (a rule of the shape
+        // only: also legal in batch_invariant mode); option "fewcout" = 0 keeps the MFMA tile.  If the sampler later fuses its solver step into this conv
+        // (EPI_DPM_STEP), the launch falls back to conv_glds's 128-pixel tile.
+        if (u->eng->option("fewcout", 1) != 0 && (u->dt == 1 || u->dt == 2) && out_f32 && epi == EPI_PLAIN && cw.cout <= 4 && segs.size() == 1 && segs[0].taps == 9 &&
+            segs[0].xform == 0 && p.seg[0].resample == 0 && p.seg[0].Hs == h && p.seg[0].Ws == w && !res && clip <= 0.f && (int64_t)h * w >= 128 * 128 && w >= 16) {
+            op.flavor = 6; op.bn = 64; op.glds_variant = 0; op.narrow = false;
+            p.tiles_x = (w + 15) / 16; p.tiles_y = (h + 15) / 16; p.img_groups = N; p.n_ntiles = 1; p.ksplit = 1; p.persist = 0;
         }
         if (p.ksplit > 64) p.ksplit = 64;
         if (!conv_set_kbounds(p, u->eng->option("splitk_weighted", 1) != 0, chunk)) return fail(TD_ERR_UNSUPPORTED, "split-K bounds: " + label);
@@ -1197,7 +1207,11 @@ static int run_unet(td_unet* u, Plan& pl, int step, const SchedCoef* fuse = null
             p.epi = EPI_DPM_STEP; p.dpm_x = (float*)pl.x->p; p.dpm_m1 = (float*)pl.m1->p; p.dpm_m2 = u->eng->option("solver_order", 2) == 3 ? (float*)pl.m2->p : nullptr; p.dpm_xin = pl.xin; p.dpm_xin_cstride = u->chunk; p.dpm_k = *fuse;
         }
         mark();
-        hipError_t e = op.flavor == 5 ? launch_conv_s16(p, u->dt, op.narrow, st)
+        if (op.flavor == 6 && p.epi != EPI_PLAIN) {   // the solver step was fused into this launch: the MFMA flavour has that epilogue
+            p.tiles_x = (p.W + 15) / 16; p.tiles_y = (p.H + 7) / 8; p.img_groups = p.N; p.n_ntiles = p.CoutPad / 64;
+        }
+        hipError_t e = op.flavor == 6 ? (p.epi == EPI_PLAIN ? launch_conv_fewcout(p, u->dt, st) : launch_conv_glds(p, u->dt, false, 64, 1, st))
+                       : op.flavor == 5 ? launch_conv_s16(p, u->dt, op.narrow, st)
                        : op.flavor == 4 ? launch_conv_sb(p, u->dt, op.narrow, op.sb_mt, op.sb_nt, st)
                        : op.flavor == 2 ? (op.glds_variant == 3 ? launch_conv_glds_wide(p, u->dt, op.bn, st) : launch_conv_glds(p, u->dt, op.narrow, op.bn, op.glds_variant, st))
                        : launch_conv(p, u->dt, op.narrow, op.bn, 0, st);
@@ -1281,7 +1295,7 @@ static const char* const kKnownOptions[] = {
     "plan_cache_mb", "plan_cache_max",
     // plan builder (speed only, or test hooks that force a tile shape; all part of the plan-cache key)
     "attn_mfma", "bn128_min_wgs", "glds", "glds_bn", "glds_bn64", "glds_dma1x1", "glds_min_wgs", "glds_round_aware", "glds_small_max_groups",
-    "glds_splitk", "glds_splitk_from_groups", "glds_splitk_max", "glds_splitk_min_groups", "glds_tiny", "glds_variant", "glds_wide", "glds_wide_min_wgs", "glds_wide_tail", "glds_wide_persist",
+    "glds_splitk", "glds_splitk_from_groups", "glds_splitk_max", "glds_splitk_min_groups", "glds_tiny", "glds_variant", "glds_wide", "glds_wide_min_wgs", "glds_wide_tail", "glds_wide_persist", "fewcout",
     "producer_act", "s16", "s16_min_wgs", "sb", "sb_m4", "sb_max_glds_wgs", "sb_mt", "sb_nt", "sb_order", "sb_splitk", "sb_splitk_max", "sb_splitk_wgs", "sb_target_wgs", "splitk",
     "splitk_target_wgs", "splitk_weighted", "walk_alternate"};
 int td_engine_set_option(td_engine* e, const char* key, int64_t value) {

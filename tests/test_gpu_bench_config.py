@@ -133,6 +133,35 @@ def test_conv_tile_variants_bit_identical(td, base, n):
         assert torch.equal(y, y0), (k, float((y - y0).abs().max()))
 
 
+def test_fewcout_output_conv_against_the_mfma_tile(td):
+    """Round 6: the decoder model's 64 -> 1 output conv on the VALU flavour (conv_fewcout.hip: one pixel per thread, fp32 multiply-adds, no 64-cout MFMA tile
+    for one cout) against the same network with the flavour off (engine option fewcout = 0: conv_glds's tile).  Same products, fp32 sums in another order:
+    the fp32 network output agrees to 1e-5 rel-RMS.  Whole tiles (256 x 256) and a ragged map (144 x 176: tiles hang over the right / bottom edge)."""
+    from oracle.unet import DECODER_CONFIG, synth_state_dict
+    from terrain_diffusion_amd.engine import get_engine
+    from oracle import rng
+    eng = get_engine("cuda")
+    m = td.EDMUnet2D(**DECODER_CONFIG, dtype="bf16").load_state_dict(synth_state_dict(DECODER_CONFIG, seed=98))
+    try:
+        for n, h, w in ((2, 256, 256), (3, 144, 176)):
+            x = torch.from_numpy(rng.standard_normal(6, (n, DECODER_CONFIG["in_channels"], h, w))).cuda()
+            t = torch.full((n,), 0.9)
+            outs, tags = {}, {}
+            for v in (0, 1):
+                eng.set_option("fewcout", v)
+                eng.set_option("profile", 1); eng.profile_read(reset=True)
+                outs[v] = m(x, t, []).clone()
+                tags[v] = [l for l, _, _ in eng.profile_ops() if l.startswith("out_conv")]
+                eng.profile_read(reset=True)
+            assert len(tags[1]) == 1 and " f6 " in tags[1][0] and " f6 " not in tags[0][0], tags
+            e = rel_rms(outs[1].cpu().numpy(), outs[0].cpu().numpy())
+            print(f"few-cout output conv {n} x {h} x {w}: vs the MFMA tile rel-RMS {e:.2e}   {tags[1][0]}")
+            assert torch.isfinite(outs[1]).all() and float(outs[1].abs().mean()) > 1e-4 and e < 1e-5, e
+    finally:
+        eng.set_option("profile", 0); eng.set_option("fewcout", 1)
+        m.close()
+
+
 def test_wide_tile_persistent_loop_same_bits(td):
     """Round 6: the wide tile's persistent tile loop (engine option glds_wide_persist = 1; conv_glds_wide.hip, PERS instantiation: 2 x CUs workgroups walk the
     launch's tiles, staging split by wave) keeps the K order of the one-tile-per-workgroup form: the decoder model's forward at 256 x 256 (its 64-channel
