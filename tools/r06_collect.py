@@ -8,12 +8,12 @@ m={'final_bench_grid8.json':'r06_bench_grid8.json','final_bench_grid8_single_lan
 'final_bench_tiles.json':'r06_bench_tiles.json','final_bench_grid8_fp16.json':'r06_bench_grid8_fp16.json','final_bench_grid8_fp32.json':'r06_bench_grid8_fp32.json',
 'final_bench_grid32_n1.json':'r06_bench_grid32_n1.json','final_per_op_batch64.txt':'r06_per_op_batch64.txt','final_per_op_batch1.txt':'r06_per_op_batch1.txt',
 'final_ttft_ttst.json':'r06_ttft_ttst_latency.json','b1_timeline.txt':'r06_batch1_timeline.txt','final_sb_layers.txt':'r06_sb_layer_battery.txt',
-'final_tests.txt':'r06_gpu_tests.txt','batch_sweep.txt':'r06_batch_sweep.txt','attn_profile.txt':'r06_attention_mfma_utilisation.txt'}
+'final_tests.txt':'r06_gpu_tests.txt','batch_sweep.txt':'r06_batch_sweep.txt','final_decoder_forward_batch4.txt':'r06_decoder_forward_batch4.txt','attn_profile.txt':'r06_attention_mfma_utilisation.txt'}
 for a,b in m.items():
     if os.path.exists(g+a) and os.path.getsize(g+a)>0: shutil.copy(g+a,'profiles/'+b)
     else: print('MISSING',a)
 open('profiles/r06_wide_tile_and_two_lanes_ab.txt','w').write('''Round 6, final build: the two structural changes of the round against each other on ONE box, interleaved, two rounds (tools/r06_final.sh -> tools/ab.sh bench):
-`python bench.py` (BASELINE configs[2]) under engine options; then the cascade (configs[4] shapes) with / without the wide tile.
+`python bench.py` (BASELINE configs[2]) under engine options; then the cascade (configs[4] shapes) without the wide tile / without the few-cout flavour / with the defaults.
   glds_wide=0,dual_stream=0 = the round-5 configuration (one sampler lane, conv_glds / conv_sb only)
   glds_wide=0               = two lanes only          dual_stream=0 = wide tile only          (empty) = the defaults          glds_wide_min_wgs=1024 = wide tile without the 16x16 level
 

@@ -11,7 +11,8 @@ timeout 600 python bench.py --dtype fp32 --steps 2 --warmup 1 --no-cpu-baseline 
 timeout 900 python bench.py --workload grid32 --steps 1 --warmup 1 --no-cpu-baseline --no-latency --no-kernel-profile > gpurun_out/final_bench_grid32_n1.json 2> gpurun_out/final_bench_grid32_n1.err
 timeout 900 bash tools/batch_sweep.sh > gpurun_out/batch_sweep.log 2>&1
 AB_ROUNDS=2 tools/ab.sh bench -- "glds_wide=0,dual_stream=0" "glds_wide=0" "dual_stream=0" "" "glds_wide_min_wgs=1024" > gpurun_out/final_ab_wide_dual.txt 2>&1
-AB_ROUNDS=1 tools/ab.sh bench --workload cascade -- "glds_wide=0" "" > gpurun_out/final_ab_cascade.txt 2>&1
+AB_ROUNDS=2 tools/ab.sh bench --workload cascade -- "glds_wide=0" "fewcout=0" "" > gpurun_out/final_ab_cascade.txt 2>&1
+TD_TOP=80 timeout 200 python tools/profile_model.py decoder 4 512 > gpurun_out/final_decoder_forward_batch4.txt 2>/dev/null
 bash tools/attn_profile.sh > gpurun_out/attn_profile.log 2>&1
 tail -12 gpurun_out/final_validate.log | cut -c1-600
 cut -c1-300 gpurun_out/final_bench_grid8_fp32.json
