@@ -237,13 +237,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // one 1-KiB LDS-DMA piece per wave: lane l copies 16 bytes from (uniform base + its own 32-bit offset) to LDS[lds_base + imm + 16*l].
 // M0 is written in the statement that uses it (it is compiler-reserved and not preserved between statements).
+// An SGPR written by the VALU (v_readfirstlane, v_readlane -- i.e. also the compiler's own reload of a SPILLED SGPR) needs five wait states before a VMEM
+// instruction reads it, and the hazard recogniser does not look inside inline asm.  The default kernels are checked for this at the ISA level
+// (tests/test_isa_contract.py, tools/isa_hazard_scan.py); where register pressure makes such reloads likely -- the persistent instantiation of the wide
+// tile, the -DTD_TRACE builds -- the guarded forms carry the wait states themselves (TD_GLDS16G: s_add_u32 + s_nop 3 = five).
+#ifdef TD_TRACE
+#define TD_SGPR_GUARD "s_nop 3\n\t"
+#define TD_SGPR_GUARD_LOAD "s_nop 4\n\t"
+#else
+#define TD_SGPR_GUARD "s_nop 0\n\t"
+#define TD_SGPR_GUARD_LOAD ""
+#endif
 #define TD_GLDS16(VOFF, SBASE, LDS_BASE, IMM)                                                                 \
-    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                          \
+    asm volatile("s_add_u32 m0, %2, %3\n\t" TD_SGPR_GUARD "global_load_lds_dwordx4 %0, %1"                     \
+                 ::"v"(VOFF), "s"(SBASE), "s"(LDS_BASE), "n"(IMM) : "memory", "scc")
+#define TD_GLDS16G(VOFF, SBASE, LDS_BASE, IMM)                                                                \
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1"                          \
                  ::"v"(VOFF), "s"(SBASE), "s"(LDS_BASE), "n"(IMM) : "memory", "scc")
 
 // one dword per lane, global -> LDS[m0 base + 4 * lane]
 #define TD_GLDS4(VOFF, SBASE, LDS_BASE, IMM)                                                                  \
-    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"                            \
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 3\n\tglobal_load_lds_dword %0, %1"                            \
                  ::"v"(VOFF), "s"(SBASE), "s"(LDS_BASE), "n"(IMM) : "memory", "scc")
 
 // a wave-uniform pointer the compiler holds in vector registers, as an SGPR pair (operand of an inline-asm "s" constraint)

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
         if ((TILE) == 18) { if (PERS && wrap) wnext = k_wpack + (size_t)pco0 * 128; else wnext += wstep; wchunk = wnext; } \
         const unsigned x_ = ((TILE) >= 9 && (TILE) < 18) ? 64u : 0u;                                         \
         if constexpr (PERS) {                                                                                \
-            _Pragma("unroll") for (int i_ = 0; i_ < NBI; ++i_) { const unsigned v_ = wvoff[i_] ^ x_; const unsigned m_ = ldsw + wslot + (unsigned)(i_ * PSTR); TD_GLDS16(v_, wnext, m_, 0); } \
+            _Pragma("unroll") for (int i_ = 0; i_ < NBI; ++i_) { const unsigned v_ = wvoff[i_] ^ x_; const unsigned m_ = ldsw + wslot + (unsigned)(i_ * PSTR); TD_GLDS16G(v_, wnext, m_, 0); } \
         } else {                                                                                             \
             { const unsigned v_ = wvoff[0] ^ x_; const unsigned m_ = ldsw + wslot; TD_GLDS16(v_, wnext, m_, 0); } \
             if constexpr (NBI > 1) { const unsigned v_ = voff1 ^ x_; const unsigned m_ = dump1 ? (unsigned)DUMP_BASE + ldsw - 2048u : ldsw + wslot + 4096u; TD_GLDS16(v_, wnext, m_, 0); } \
@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel_wide(const ConvParams
         if constexpr (PERS) src_ = td_uniform_ptr(src_);   /* (hipcc keeps the segment pointer of the tile loop in a VGPR pair and hands THAT to the "s" operand) */ \
         _Pragma("unroll") for (int it_ = 0; it_ < A_ITERS; ++it_) {                                    \
             const unsigned o_ = (unsigned)(aoff[it_] >= 0 ? aoff[it_] : 0) * (unsigned)sizeof(T);      \
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(av[it_]) : "v"(o_), "s"(src_) : "memory"); \
+            if constexpr (PERS) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(av[it_]) : "v"(o_), "s"(src_) : "memory");   /* (guarded: conv_common.h, TD_GLDS16G) */ \
+            else asm volatile(TD_SGPR_GUARD_LOAD "global_load_dwordx4 %0, %1, %2" : "=&v"(av[it_]) : "v"(o_), "s"(src_) : "memory"); \
         }                                                                                              \
     }
 #define TDW_PIN_R(I0, I1) { _Pragma("unroll") for (int it_ = (I0); it_ < (I1); ++it_) asm volatile("" : "+v"(av[it_])); }

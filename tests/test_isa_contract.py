@@ -28,14 +28,6 @@ def _regs(text):
     return out
 
 
-def _sregs(text):
-    out = set()
-    for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", text):
-        out.update(range(int(a), int(b) + 1))
-    out.update(int(a) for a in re.findall(r"\bs(\d+)\b", text))
-    return out
-
-
 @pytest.fixture(scope="module")
 def wide_isa(tmp_path_factory):
     if shutil.which("hipcc") is None:
@@ -58,13 +50,15 @@ def wide_isa(tmp_path_factory):
             name = None
         elif name:
             body.append(line)
-    # template arguments <T, BN, TAIL, PERS>: ...ELb<TAIL>ELb<PERS>E...; the default plan launches PERS = 0 only
-    return {k: v for k, v in funcs.items() if re.search(r"ELb[01]ELb0E", k)}
+    return funcs
 
 
 def test_asm_loaded_registers_are_untouched_until_their_pin(wide_isa):
-    assert len(wide_isa) == 8, sorted(wide_isa)   # {bf16, fp16} x {96, 64} x {3x3 only, with a 1x1 tail}
-    for fn, body in wide_isa.items():
+    # template arguments <T, BN, TAIL, PERS>: ...ELb<TAIL>ELb<PERS>E...; the default plan launches PERS = 0 only.  (In the persistent instantiation the two
+    # staging roles live in different wave-uniform branches, whose register use a linear scan cannot tell apart: its guard is the bit-identity test on the GPU.)
+    default = {k: v for k, v in wide_isa.items() if re.search(r"ELb[01]ELb0E", k)}
+    assert len(default) == 8 and len(wide_isa) == 10, sorted(wide_isa)   # {bf16, fp16} x {96, 64} x {3x3 only, with a 1x1 tail}; + the persistent 64-cout tile
+    for fn, body in default.items():
         in_asm, flight, loads, pins, bad = False, {}, 0, 0, []
         for i, line in enumerate(body):
             t = line.strip()
@@ -95,32 +89,12 @@ def test_asm_loaded_registers_are_untouched_until_their_pin(wide_isa):
         assert not flight, (fn, "asm loads without a pin behind them", sorted(flight)[:8])
 
 
-def test_no_readfirstlane_right_in_front_of_an_asm_vmem_instruction(wide_isa):
+def test_no_valu_written_sgpr_right_in_front_of_an_asm_vmem_instruction(wide_isa):
+    """Every instantiation, the persistent one included (its DMA / load forms carry the wait states themselves: TD_GLDS16G).  The same scan over the whole
+    library: python tools/isa_hazard_scan.py (~5 min of compilation)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_hazard_scan", os.path.join(ROOT, "tools", "isa_hazard_scan.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     for fn, body in wide_isa.items():
-        code = []   # (text, inside inline asm)
-        in_asm = False
-        for line in body:
-            t = line.strip()
-            if "#ASMSTART" in t:
-                in_asm = True; continue
-            if "#ASMEND" in t:
-                in_asm = False; continue
-            if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
-                continue
-            code.append((t.split(";")[0].strip(), in_asm))
-        for i, (t, a) in enumerate(code):
-            if not a or not t.startswith("global_load"):
-                continue
-            need = _sregs(t)
-            if not need:
-                continue
-            states = 0   # wait states between a VALU write of one of those SGPRs and this instruction: five are required
-            for j in range(i - 1, max(-1, i - 8), -1):
-                u = code[j][0]
-                if u.startswith("v_readfirstlane_b32") or u.startswith("v_readlane_b32"):
-                    dst = _sregs(u.split(",")[0])
-                    assert not (dst & need) or states >= 5, (fn, u, t, states)
-                m = re.match(r"s_nop (\d+)", u)
-                states += (int(m.group(1)) + 1) if m else 1
-                if states >= 5:
-                    break
+        bad = mod.scan(body)
+        assert not bad, (fn, bad[:4])
