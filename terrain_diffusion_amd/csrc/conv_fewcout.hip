@@ -45,13 +45,21 @@ __global__ __launch_bounds__(256) void conv_fewcout_kernel(const ConvParams p) {
     for (int c = 0; c < CO; ++c) acc[c][0] = acc[c][1] = 0.f;
     for (int ch = 0; ch < nch; ++ch) {
         if (ch) __syncthreads();   // everybody is done with the previous chunk
-        // ---- the chunk's 18 x 18 x 64-channel patch: 16-byte pieces, zero outside the image
-        for (int e = tid; e < NPATCH * 8; e += 256) {
-            const int pp = e >> 3, q = e & 7, py = pp / PW, px = pp - py * PW;
+        // ---- the chunk's 18 x 18 x 64-channel patch: 16-byte pieces, zero outside the image.  All of a thread's loads first, then its LDS writes (first
+        // build: a rolled loop of load -> wait -> write, i.e. eleven HBM round trips in series per workgroup: 84 / 67 us per launch instead of ~45)
+        constexpr int NIT = (NPATCH * 8 + 255) / 256;   // 11
+        u32x4 pv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + it * 256, pp = e >> 3, q = e & 7, py = pp / PW, px = pp - py * PW;
             const int y = y0 + py - 1, x = x0 + px - 1;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (y >= 0 && y < H && x >= 0 && x < W) v = *(const u32x4*)(src + ((size_t)((n0 * H + y) * W + x) * cs + ch * CHUNK + q * 8));
-            *(u32x4*)(smem + pp * PITCH + q * 16) = v;
+            pv[it] = u32x4{0u, 0u, 0u, 0u};
+            if (e < NPATCH * 8 && y >= 0 && y < H && x >= 0 && x < W) pv[it] = *(const u32x4*)(src + ((size_t)((n0 * H + y) * W + x) * cs + ch * CHUNK + q * 8));
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + it * 256;
+            if (e < NPATCH * 8) *(u32x4*)(smem + (e >> 3) * PITCH + (e & 7) * 16) = pv[it];
         }
         // ---- its weights: [tap][cout][piece], the slab's slot swizzle undone
         for (int e = tid; e < 9 * CO * 8; e += 256) {

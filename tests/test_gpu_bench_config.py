@@ -133,17 +133,19 @@ def test_conv_tile_variants_bit_identical(td, base, n):
         assert torch.equal(y, y0), (k, float((y - y0).abs().max()))
 
 
-def test_fewcout_output_conv_against_the_mfma_tile(td):
-    """Round 6: the decoder model's 64 -> 1 output conv on the VALU flavour (conv_fewcout.hip: one pixel per thread, fp32 multiply-adds, no 64-cout MFMA tile
+@pytest.mark.parametrize("out_channels", [1, 2, 3])
+def test_fewcout_output_conv_against_the_mfma_tile(td, out_channels):
+    """Round 6: the decoder model's 64 -> 1 output conv (and the same network with 2 / 3 output channels: the flavour's two other instantiations) on the VALU flavour (conv_fewcout.hip: one pixel per thread, fp32 multiply-adds, no 64-cout MFMA tile
     for one cout) against the same network with the flavour off (engine option fewcout = 0: conv_glds's tile).  Same products, fp32 sums in another order:
     the fp32 network output agrees to 1e-5 rel-RMS.  Whole tiles (256 x 256) and a ragged map (144 x 176: tiles hang over the right / bottom edge)."""
     from oracle.unet import DECODER_CONFIG, synth_state_dict
     from terrain_diffusion_amd.engine import get_engine
     from oracle import rng
     eng = get_engine("cuda")
-    m = td.EDMUnet2D(**DECODER_CONFIG, dtype="bf16").load_state_dict(synth_state_dict(DECODER_CONFIG, seed=98))
+    cfg = dict(DECODER_CONFIG, out_channels=out_channels)
+    m = td.EDMUnet2D(**cfg, dtype="bf16").load_state_dict(synth_state_dict(cfg, seed=98))
     try:
-        for n, h, w in ((2, 256, 256), (3, 144, 176)):
+        for n, h, w in ((2, 256, 256), (3, 144, 176)) if out_channels == 1 else ((2, 144, 176),):
             x = torch.from_numpy(rng.standard_normal(6, (n, DECODER_CONFIG["in_channels"], h, w))).cuda()
             t = torch.full((n,), 0.9)
             outs, tags = {}, {}
