@@ -121,6 +121,9 @@ __global__ __launch_bounds__(256) void attn_pack_qkv64_kernel(const TIN* __restr
     Vt[(bh * 64 + lane) * Lkp + pk] = (__bf16)(x[2] * inv[2]);   // padded keys: zeros
 }
 
+#ifndef TD_ATTN_ABL
+#define TD_ATTN_ABL 0   // ablation hooks of the pipelined loop (tools/r06_attn_ablate.sh; wrong results by design): 1 no barrier, 2 no staging, 8 no S MFMAs, 16 no PV MFMAs
+#endif
 #ifndef TD_ATTN_THR
 #define TD_ATTN_THR 8
 #endif
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256) void attn_pack_qkv64_kernel(const TIN* __restr
 #endif
 
 // DP16 = Dp / 16 (k-steps of Q K^T), DM32 = Dm / 32 (row blocks of O^T)
-template <int DP16, int DM32, int NW, bool FOLD>
+template <int DP16, int DM32, int NW, bool FOLD, bool PIPE = false>
 __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __restrict__ Qp, const __bf16* __restrict__ Kp, const __bf16* __restrict__ Vt, float* __restrict__ out_f32,
                                                         __bf16* __restrict__ out_b16, AttnStrides ost, int Lq, int Lk, int Lkp, int D) {
     constexpr int Dp = DP16 * 16, Dm = DM32 * 32, TK = 64;
@@ -198,6 +201,226 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
     // two tiles in registers and copied one register set to the other every tile: 10 % of a tile's cycles in the phase trace.)  Loads are
     // unconditional with the tile index clamped; the store of a tile that does not exist lands in a buffer nobody reads again.
     const int nt_ = (Lk + TK - 1) / TK;
+    if constexpr (PIPE) {
+    // ---- Software-pipelined tile loop (round 6; plain softmax form with an even DP16, or the folded form).  In the loop below a wave's three phases of a tile are serial -- S MFMAs, ~1000 cycles
+    // of softmax VALU, PV MFMAs (phase trace at d = 64: 526 + 1092 + 521 of 3021 cycles per tile and wave) -- and only the SIMD's other wave fills the holes.  Here the
+    // matrix work of a tile is issued IN THE SHADOW of the vector work of the same wave: the staged tile t is { K(t+1), V^T(t) }; iteration t issues S(t+1) = K(t+1) Q^T
+    // into the second score set while the softmax of S(t) (computed during iteration t-1) runs, then O += V^T(t) P(t) step by step behind the probabilities as they
+    // appear.  Program order is pinned by sched_barriers: [S slice | max], [S slice | max, exchange, reference point], (rescale), [S slices | exp chunk 0],
+    // [PV step 0 | exp chunk 1], [PV 1 | exp 2], [PV 2 | exp 3], [PV 3]; the fragments of a region are read from LDS one region ahead.  Same MFMAs,
+    // same operand order, same softmax arithmetic as the unpipelined loop -- the same bits (tools/attn_bench.hip TD_ATTN_DUMP, cmp against TD_ATTN_PIPE=0).
+    static_assert(FOLD || DP16 % 2 == 0, "pipelined loop, plain softmax form: even number of k-steps (four equal S slices)");
+    // staged tiles travel global -> registers -> LDS; TWO register sets (the loop is unrolled by two, so the sets alternate without copies): a tile is requested two
+    // iterations before it is written to LDS (one iteration of lead left the LDS writes waiting for their loads: 8 % of a tile in the phase trace of the unpipelined loop)
+    u32x4 kreg2[KIT], vreg2[VIT];
+    auto load_k = [&](u32x4 (&kr)[KIT], int krow0) {
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) {
+            const int e0 = tid + it * NTHR, e = e0 < KPIECES ? e0 : KPIECES - 1, r = e / (Dp / 8), sl = e % (Dp / 8);
+            const int row = krow0 + r < Lk ? krow0 + r : Lk - 1;
+            kr[it] = *(const u32x4*)(kbase + (long)row * Dp + sl * 8);
+        }
+    };
+    auto load_v = [&](u32x4 (&vr)[VIT], int t) {
+        const int k0 = (t < nt_ ? t : nt_ - 1) * TK;
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            const int e0 = tid + it * NTHR, e = e0 < VPIECES ? e0 : VPIECES - 1, r = e / (TK / 8), sl = e % (TK / 8);
+            vr[it] = *(const u32x4*)(vbase + (long)r * Lkp + k0 + sl * 8);
+        }
+    };
+    auto store_k = [&](const u32x4 (&kr)[KIT], int bf) {
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) {
+            const int e = tid + it * NTHR, r = e / (Dp / 8), sl = e % (Dp / 8);
+            if (KPIECES % NTHR == 0 || e < KPIECES) *(u32x4*)(s_k[bf] + r * KPITCH + sl * 16) = kr[it];
+        }
+    };
+    auto store_v = [&](const u32x4 (&vr)[VIT], int bf) {
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            const int e = tid + it * NTHR, r = e / (TK / 8), sl = e % (TK / 8);
+            if (VPIECES % NTHR == 0 || e < VPIECES) *(u32x4*)(s_v[bf] + r * VPITCH + sl * 16) = vr[it];
+        }
+    };
+    // S MFMA i of a tile: k-step i / 2, key block i % 2 (consecutive MFMAs alternate accumulators), issued in four slices [SB[j], SB[j+1]).  Folded form: the
+    // reference channel of Q sits in the LAST k-step (D / 16 = DP16 - 1), so the last two MFMAs form slices 2 and 3 -- issued behind the point where the reference
+    // may move and the Q fragment is rewritten: S(t+1) always comes out relative to the reference the softmax of tile t+1 will assume.
+    constexpr int MS = DP16 * 2;
+    constexpr int SB[5] = {0, FOLD ? (MS - 1) / 2 : MS / 4, FOLD ? MS - 2 : MS / 2, FOLD ? MS - 1 : 3 * MS / 4, MS};
+    auto kfrag = [&](const unsigned char* sk_, int i) { return *(const u32x4*)(sk_ + ((i & 1) * 32 + l31) * KPITCH + (i >> 1) * 32 + lh * 16); };
+    auto vfrag = [&](const unsigned char* sv_, int st4, int d) { return *(const u32x4*)(sv_ + (d * 32 + l31) * VPITCH + st4 * 32 + lh * 16); };
+    f32x16 sa[2], sb[2];
+    // prologue: K(0) through the second buffer for S(0); staged tile 0 into the first; staged tile 1 requested
+    load_k(kreg, 0); store_k(kreg, 1);
+    load_k(kreg, TK); load_v(vreg, 0); store_k(kreg, 0); store_v(vreg, 0);
+    load_k(kreg2, 2 * TK); load_v(vreg2, 1);   // staged tile 1 (written to LDS by iteration 0) in the second set
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sa[kb][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MS; ++i) sa[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfrag(s_k[1], i)), __builtin_bit_cast(bf16x8, qf[i >> 1]), sa[i & 1], 0, 0, 0);
+    __syncthreads();   // K(0)'s readers are done before iteration 0 writes staged tile 1 there
+    auto body = [&](auto bufc, f32x16 (&sc)[2], f32x16 (&sn)[2], const int t) {
+        constexpr bool BUF = decltype(bufc)::value != 0;
+        const int k0 = t * TK;
+        const unsigned char* sk_ = s_k[BUF];
+        const unsigned char* sv_ = s_v[BUF];
+        u32x4 kfr[MS];   // K fragments of the next tile's S MFMAs: slice j is read from LDS one region ahead of its MFMAs
+#pragma unroll
+        for (int i = SB[0]; i < SB[1]; ++i) kfr[i] = kfrag(sk_, i);   // (in front of the LDS writes: the LDS pipe serves in order)
+        __builtin_amdgcn_sched_barrier(0);
+        // staged tile t+2 = { K(t+3), V^T(t+2) } is requested here and written to LDS near the end of iteration t+1 (into the buffer iteration t+1 does not read):
+        // almost two iterations of lead, and the wait in front of the LDS writes comes AFTER this iteration's requests, so hipcc's wait-count pass can tell the two
+        // sets apart (with the writes at the top of the loop it waited for everything but one load: the loop header merges the prologue's and the back edge's state)
+#if !(TD_ATTN_ABL & 2)
+        if constexpr (BUF) { load_k(kreg2, (t + 3) * TK); load_v(vreg2, t + 2); } else { load_k(kreg, (t + 3) * TK); load_v(vreg, t + 2); }
+#endif
+        if (k0 + TK > Lk) {  // wave-uniform: only the last tile of a ragged key length
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + kb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+                    if (key >= Lk) sc[kb][r] = -3.0e38f;
+                }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sn[kb][r] = 0.f;
+        auto sslice = [&](int j) {   // the MFMAs of slice j; the fragments of slice j + 1
+            if (j < 3) {
+#pragma unroll
+                for (int i = SB[j + 1]; i < SB[j + 2]; ++i) kfr[i] = kfrag(sk_, i);
+            }
+#pragma unroll
+            for (int i = SB[j]; i < SB[j + 1]; ++i) {
+#if TD_ATTN_ABL & 8
+                asm volatile("" : "+v"(sn[i & 1]) : "v"(kfr[i]));
+#else
+                sn[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr[i]), __builtin_bit_cast(bf16x8, qf[i >> 1]), sn[i & 1], 0, 0, 0);
+#endif
+            }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        // region 1: S slice 0 | first half of the maximum
+        sslice(0);
+        float mt = fmaxf(sc[0][0], sc[0][1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) mt = fmaxf(fmaxf(mt, sc[0][r]), sc[0][r + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // region 2: S slice 1 | second half of the maximum, exchange, reference point (deferred maximum: see the unpipelined loop)
+        sslice(1);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mt = fmaxf(fmaxf(mt, sc[1][r]), sc[1][r + 1]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        bool moved;
+        float m_new = 0.f, alpha = 1.f;
+        if constexpr (FOLD) {
+            m_run = fmaxf(m_run, mt);   // (FOLD: the running maximum RELATIVE to m_ref; sc already is logit - m_ref)
+            moved = __builtin_amdgcn_ballot_w64(mt > (float)TD_ATTN_THR || m_run < -64.f) != 0;
+        } else {
+            moved = __builtin_amdgcn_ballot_w64(mt > m_run + (float)TD_ATTN_THR) != 0;
+            m_new = moved ? fmaxf(m_run, mt) : m_run;
+            alpha = moved ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (moved) {
+            if constexpr (FOLD) {
+                // as in the unpipelined loop: new reference = the running maximum rounded to bf16, this tile's scores corrected, the factor clamped for a reference
+                // that falls in a query's first tile, the reference channel of the Q fragment (last k-step) rewritten -- in front of S slices 2 and 3, which read it
+                const float mr_new = (float)(__bf16)(m_ref + m_run), delta = mr_new - m_ref;
+                alpha = __builtin_amdgcn_exp2f(fminf(-delta, 64.f));
+                m_ref = mr_new; m_run -= delta;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[kb][r] -= delta;
+                const unsigned nb = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)(-mr_new));
+                const int e16 = D & 15;
+                if (lh == (e16 >> 3)) {
+                    const int dw = (e16 & 7) >> 1, hi = e16 & 1;
+#pragma unroll
+                    for (int w_ = 0; w_ < 4; ++w_)
+                        if (w_ == dw) qf[DP16 - 1][w_] = hi ? ((qf[DP16 - 1][w_] & 0x0000ffffu) | (nb << 16)) : ((qf[DP16 - 1][w_] & 0xffff0000u) | nb);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < DM32; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
+        float psum_e = 0.f, psum_o = 0.f;
+        bf16x8 pb[4];   // B fragments of the four 16-key steps: 8 probabilities each, already in contraction order
+        auto ehalf = [&](int c, int hh) {
+            const int kb = c >> 1, jj = c & 1;
+#pragma unroll
+            for (int e = hh * 4; e < hh * 4 + 4; e += 2) {
+                if constexpr (FOLD) {   // neither the subtraction nor the row sum: both on the matrix pipe (attn_fold)
+                    pb[c][e] = (__bf16)__builtin_amdgcn_exp2f(sc[kb][jj * 8 + e]);
+                    pb[c][e + 1] = (__bf16)__builtin_amdgcn_exp2f(sc[kb][jj * 8 + e + 1]);
+                } else {
+                    const float p0 = __builtin_amdgcn_exp2f(sc[kb][jj * 8 + e] - m_new);
+                    const float p1 = __builtin_amdgcn_exp2f(sc[kb][jj * 8 + e + 1] - m_new);
+                    psum_e += p0; psum_o += p1;
+                    pb[c][e] = (__bf16)p0; pb[c][e + 1] = (__bf16)p1;
+                }
+            }
+            if constexpr (!FOLD) asm volatile("" : "+v"(psum_e), "+v"(psum_o));   // the running sums stay in this region (without the pin all 32 additions sink behind the tile's last MFMA)
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        // region 3: S slice 2 | first half of exp chunk 0
+        sslice(2);
+        ehalf(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // region 4: S slice 3 | second half of exp chunk 0
+        u32x4 va[DM32], vb[DM32];
+#pragma unroll
+        for (int d = 0; d < DM32; ++d) va[d] = vfrag(sv_, 0, d);
+        sslice(3);
+        ehalf(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // regions 5 .. 8: PV step s (V^T fragments read one region ahead) | exp chunk s + 1
+#pragma unroll
+        for (int st4 = 0; st4 < 4; ++st4) {
+            u32x4 (&vc)[DM32] = (st4 & 1) ? vb : va;
+            u32x4 (&vn)[DM32] = (st4 & 1) ? va : vb;
+            if (st4 < 3) {
+#pragma unroll
+                for (int d = 0; d < DM32; ++d) vn[d] = vfrag(sv_, st4 + 1, d);
+            }
+#pragma unroll
+            for (int d = 0; d < DM32; ++d) {
+#if TD_ATTN_ABL & 16
+                asm volatile("" : "+v"(o[d]) : "v"(vc[d]), "v"(pb[st4]));
+#else
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vc[d]), pb[st4], o[d], 0, 0, 0);
+#endif
+            }
+            if (st4 < 3) { ehalf(st4 + 1, 0); ehalf(st4 + 1, 1); }
+            if (st4 == 2) {   // staged tile t+1 (requested during iteration t-1) -> the other LDS buffer
+#if !(TD_ATTN_ABL & 2)
+                if constexpr (BUF) { store_k(kreg, 0); store_v(vreg, 0); } else { store_k(kreg2, 1); store_v(vreg2, 1); }
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!FOLD) {
+            l_run = l_run * alpha + (psum_e + psum_o);
+            m_run = m_new;
+        }
+#if !(TD_ATTN_ABL & 1)
+        __syncthreads();
+#endif
+    };
+    for (int t = 0; t < nt_; t += 2) {
+        body(std::integral_constant<int, 0>{}, sa, sb, t);
+        if (t + 1 < nt_) body(std::integral_constant<int, 1>{}, sb, sa, t + 1);
+    }
+    } else {
     load_tile(0);
     store_tile(0);
     load_tile(nt_ > 1 ? TK : 0);
@@ -360,6 +583,7 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const __bf16* __rest
     }
     out_b16 = nullptr;
 #endif
+    }   // (unpipelined loop)
     float linv;
     if constexpr (FOLD) {
         // row D of O^T is the denominator: register r, lane half lhl of 32-row block D / 32 (row = 8 (r / 4) + 4 lh + r % 4)
@@ -418,8 +642,18 @@ static hipError_t attn_mfma(const __bf16* Qp, const __bf16* Kp, const __bf16* Vt
     // 8 waves (256 queries) per workgroup when there are enough queries to fill the chip that way: the K / V^T tile is staged once per workgroup
     static const long big_min = getenv("TD_ATTN_BIG_MIN") ? atol(getenv("TD_ATTN_BIG_MIN")) : 256;   // A/B hook (tools/attn_bench.py)
     const bool big = (long)((Lq + 255) / 256) * H * B >= big_min;
+    static const int pipe_env = getenv("TD_ATTN_PIPE") ? atoi(getenv("TD_ATTN_PIPE")) : 1;   // A/B hook: 0 = the unpipelined loop everywhere
+    // the software-pipelined loop: long key sequences (short ones lose more to the pipeline's fill -- one more staged K tile, two more barriers -- than they gain) on grids
+    // that leave a CU one workgroup (with two or more, the other workgroup's waves already fill a wave's serial phases: measured level at 512 workgroups); head dims <= 64 (above, the hot-loop gain
+    // is 1 - 4 % and isolated launches of the d = 128 problem LOSE 9 %: 256 VGPRs + scratch; d = 160 spills outright) -- profiles/r06_attention_pipelined_loop.txt
+    static const int pipe_min = getenv("TD_ATTN_PIPE_MIN") ? atoi(getenv("TD_ATTN_PIPE_MIN")) : 512;
+    static const long pipe_max_wgs = getenv("TD_ATTN_PIPE_MAX_WGS") ? atol(getenv("TD_ATTN_PIPE_MAX_WGS")) : 384;
+    const long nwgs = (long)(big ? (Lq + 255) / 256 : (Lq + 127) / 128) * H * B;
+    const bool pipe = pipe_env != 0 && Lk >= pipe_min && nwgs <= pipe_max_wgs;
     const dim3 grid(big ? (Lq + 255) / 256 : (Lq + 127) / 128, H, B), blk(big ? 512 : 256);
 #define TD_ATTN_CASE(A, M, F) if (Dp16 == A && Dm32 == M && fold == F) {                                                                        \
+        if constexpr ((F || A % 2 == 0) && A <= 4) if (pipe && big) { hipLaunchKernelGGL((attn_mfma_kernel<A, M, 8, F, true>), grid, blk, 0, st, Qp, Kp, Vt, out_f32, out_b16, ost, Lq, Lk, Lkp, D); return hipGetLastError(); } \
+        if constexpr ((F || A % 2 == 0) && A <= 4) if (pipe) { hipLaunchKernelGGL((attn_mfma_kernel<A, M, 4, F, true>), grid, blk, 0, st, Qp, Kp, Vt, out_f32, out_b16, ost, Lq, Lk, Lkp, D); return hipGetLastError(); } \
         if (big) hipLaunchKernelGGL((attn_mfma_kernel<A, M, 8, F>), grid, blk, 0, st, Qp, Kp, Vt, out_f32, out_b16, ost, Lq, Lk, Lkp, D);        \
         else hipLaunchKernelGGL((attn_mfma_kernel<A, M, 4, F>), grid, blk, 0, st, Qp, Kp, Vt, out_f32, out_b16, ost, Lq, Lk, Lkp, D);            \
         return hipGetLastError(); }

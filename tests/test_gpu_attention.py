@@ -32,6 +32,13 @@ CASES = [  # B, H, Lq, Lk, D, normalize
     (1, 1, 100, 77, 40, False),     # ragged: not multiples of the 128-query / 64-key tiles
     (2, 1, 1, 130, 8, False),
     (1, 2, 129, 65, 96, True),
+    # round 6, software-pipelined loop (>= 512 keys, head dims 32 / 64 / 96 / 128): its LEAN form (d <= 64: reference point in the accumulator input, row sum on the
+    # matrix pipe) and its plain form; even / odd tile counts, ragged last tile, one query block and several
+    (1, 2, 1024, 1024, 64, True),
+    (1, 2, 700, 1000, 64, False),
+    (1, 2, 520, 513, 32, False),
+    (1, 1, 200, 600, 96, False),
+    (1, 1, 300, 640, 128, False),
 ]
 
 
@@ -75,15 +82,17 @@ def test_attention_arbitrary_scale_long_keys_d40(scale):
     assert e32 < 1.5e-2 and e16 < 6e-3 and e16s < 4e-3
 
 
+@pytest.mark.parametrize("D", [40, 64, 128])
 @pytest.mark.parametrize("shift,spread", [(-300.0, 1.0), (250.0, 1.0), (0.0, 40.0)])
-def test_attention_folded_reference_point_moves_both_ways(shift, spread):
-    """Round 6: at head dims with padding (D % 16 != 0) the softmax's reference point rides in a padding channel of the Q K^T contraction and starts at 0
+def test_attention_folded_reference_point_moves_both_ways(shift, spread, D):
+    """(D = 64: the pipelined loop's LEAN form keeps the same kind of reference point -- in the accumulator input of the S MFMAs, corrected one tile late after a move;
+    D = 128: the pipelined loop's plain form, for comparison.)  Round 6: at head dims with padding (D % 16 != 0) the softmax's reference point rides in a padding channel of the Q K^T contraction and starts at 0
     (csrc/attn_mfma.hip, attn_fold).  It has to move DOWN when every logit of a query lies far below it (shift -300: exp2 of the raw logits would underflow
     to a zero row sum), UP when they lie far above (shift +250: overflow), and repeatedly when the maxima keep growing along the keys (spread 40: logits of
     increasing magnitude; the in-register Q fragment is rewritten on each move).  Logits are shifted by adding a constant channel pair to q and k."""
     from terrain_diffusion_amd.attention import attention
     g = torch.Generator().manual_seed(606)
-    D, Lq, Lk = 40, 200, 700
+    Lq, Lk = 200, 700
     q, k, v = (torch.randn(1, 2, L, D, generator=g) for L in (Lq, Lk, Lk))
     scale = 1.0 / math.sqrt(D)
     # channel 0: q = c, k = shift / (c * scale)  ->  every logit gets +shift (in natural-log units); bf16 rounds c and the quotient, the reference uses the rounded values

@@ -71,7 +71,7 @@ def figures():
         m = re.search(r"4096x4096 d(\d+) .*kernel ([0-9.]+) us .*mfma_busy ([0-9.]+) %", l)
         if m:
             at[int(m.group(1))] = (float(m.group(2)), float(m.group(3)))
-    f.update(a40_us=at[40][0], a40=at[40][1], a64=at[64][1], a128=at[128][1], a160=at[160][1])
+    f.update(a40_us=at[40][0], a40=at[40][1], a64=at[64][1], a64_us=at[64][0], a128=at[128][1], a160=at[160][1])
     tl = open(os.path.join(P, "r06_gpu_tests.txt")).read(); m = re.search(r"(\d+) passed, (\d+) skipped", tl); f.update(passed=int(m.group(1)), skipped=int(m.group(2)))
     f["dec_ms"] = float(re.search(r"([0-9.]+) ms kernel time", open(os.path.join(P, "r06_decoder_forward_batch4.txt")).readline()).group(1))
     f["fc_us"] = float([l for l in open(os.path.join(P, "r06_decoder_forward_batch4.txt")) if "out_conv" in l][0].split()[0])
@@ -108,7 +108,7 @@ TEMPLATE = """* default bench (`python bench.py`, BASELINE configs[2], `profiles
   this collection's box (25.5–25.9 on the earlier ones), its 2.8 TB/s was not. TTFT / TTST {ttft:.1f} / {ttst:.1f} ms (68.5 / 24.1).
 * `strong_scaling_anchor` (configs[3] on one rank, default plan, same run): **{anchor:.2f} MP/s** (round 5, batch-invariant: 15.50), {anchor_ms:.1f} ms per 64-window batch; the full grid32 line on one rank
   (`r06_bench_grid32_n1.json`): {grid32:.2f} MP/s. Independent tiles: {tiles:.1f} MP/s (61.9). fp16 storage on grid8: {g16:.2f} MP/s (18.57). Exact-fp32 mode: {g32:.2f} MP/s, {g32_frac:.2f} of the fp32 MFMA peak.
-* attention (`r06_attention_mfma_utilisation.txt`): SD 4096² d40 **{a40_us:.1f} µs, MFMA busy {a40:.1f} %** (round 4/5: 91.2 µs, 28.5 %); d64 / d128 / d160 {a64:.1f} / {a128:.1f} / {a160:.1f} % (unchanged kernels).
+* attention (`r06_attention_mfma_utilisation.txt`; with the software-pipelined tile loop, `r06_attention_pipelined_loop.txt`): SD 4096² d40 **{a40_us:.1f} µs, MFMA busy {a40:.1f} %** (round 4/5: 91.2 µs, 28.5 %; the fifth collection, folded softmax only: 76.9 µs, 33.8 %); d64 **{a64_us:.1f} µs, {a64:.1f} %** (100.8 µs, 29.8 %); d128 / d160 {a128:.1f} / {a160:.1f} % (d160 keeps the unpipelined loop).
 * GPU tests at this build: **{passed} passed, {skipped} skipped** (the two two-GPU tests; `r06_gpu_tests.txt`); smoke rel-RMS vs oracle 5.7e-3. CPU baseline (oracle, 16 of 256 host threads): {cpu:.3f} MP/s.
 """
 
