@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-end validation on one MI355X: GPU test suite, smoke, default bench (with cpu_baseline), cascade bench
 cd $GRAFT_REPO_ROOT
-timeout 1800 python -m pytest tests -q -m gpu --durations=10 > gpurun_out/final_tests.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/final_tests.txt
+if [ -z "$SKIP_TESTS" ]; then timeout 1800 python -m pytest tests -q -m gpu --durations=10 > gpurun_out/final_tests.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/final_tests.txt; fi   # SKIP_TESTS=1: a second collection of the SAME build on another box keeps the first one's test record
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/final_smoke.txt 2>&1
 timeout 900 python bench.py > gpurun_out/final_bench_grid8.json 2> gpurun_out/final_bench_grid8.err
 timeout 600 python bench.py --workload cascade --steps 3 --warmup 1 > gpurun_out/final_bench_cascade.json 2> gpurun_out/final_bench_cascade.err

@@ -13,7 +13,7 @@ timeout 900 bash tools/batch_sweep.sh > gpurun_out/batch_sweep.log 2>&1
 AB_ROUNDS=2 tools/ab.sh bench -- "glds_wide=0,dual_stream=0" "glds_wide=0" "dual_stream=0" "" "glds_wide_min_wgs=1024" > gpurun_out/final_ab_wide_dual.txt 2>&1
 AB_ROUNDS=2 tools/ab.sh bench --workload cascade -- "glds_wide=0" "fewcout=0" "" > gpurun_out/final_ab_cascade.txt 2>&1
 TD_TOP=80 timeout 200 python tools/profile_model.py decoder 4 512 > gpurun_out/final_decoder_forward_batch4.txt 2>/dev/null
-bash tools/attn_profile.sh > gpurun_out/attn_profile.log 2>&1
+if [ -z "$SKIP_TESTS" ]; then bash tools/attn_profile.sh > gpurun_out/attn_profile.log 2>&1; fi
 tail -12 gpurun_out/final_validate.log | cut -c1-600
 cut -c1-300 gpurun_out/final_bench_grid8_fp32.json
 tail -12 gpurun_out/batch_sweep.txt
