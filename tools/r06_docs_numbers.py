@@ -89,10 +89,10 @@ TEMPLATE = """* default bench (`python bench.py`, BASELINE configs[2], `profiles
   The 8×8 level (440 launches, conv_sb): {sb:.0f} TFLOP/s.
 * **box spread.** The conv kernels have not changed since the fifth collection; the last four collections differ in `conv_fewcout.hip` and the attention kernel only. The sixth's box
   (build `ce275468cb4e32e1`; line and trace summary kept as `r06_bench_grid8_sixth_collection_build_ce275468*.`) gave **21.68 MP/s, family 0.421 lane-aware / 0.407 one lane / 0.412 from
-  the trace**; the seventh (build `1aaa9aea…`) 20.93; the final build on two boxes 20.03 and 20.11 (`r06_bench_grid8_final_build_second_box.json`), family 0.387 / 0.389. The per-layer tables
+  the trace**; the seventh (build `1aaa9aea…`) 20.93; the final build on FOUR boxes 20.03 / 20.11 / 20.92 / 20.86 (`r06_bench_grid8.json`, `r06_bench_grid8_final_build_{second,third,fourth}_box.json`), family 0.387 / 0.389 / 0.404 / 0.403. The per-layer tables
   say what differs: the MFMA-dense layers are 6–8 % slower on the later boxes (dec.512x512_up.conv_res1 583 → 621 µs) while the latency-bound kernels are not (attention block 43.0 → 42.7 µs,
   qkv conv 39.8 → 38.6) — the power-limited shader clock of §4 "conv throughput", which is a property of the chip (and of what its neighbours on the node are doing), not of the build. The
-  review's ≥ 0.40 on the driver line was reached on the first six boxes of the round (0.408–0.421) and missed on the final build's two (0.387 / 0.389); the seventh (20.93 MP/s) lay between.
+  review's ≥ 0.40 on the driver line was reached on the first six boxes of the round (0.408–0.421) and on two of the final build's four (0.404 / 0.403), missed on its other two (0.387 / 0.389).
 * the two changes against each other (`r06_wide_tile_and_two_lanes_ab.txt`, one box, interleaved twice): round-5 configuration {ab_r5:.2f} MP/s; two lanes only {ab_lanes:.2f} ({p_lanes:+.1f} %); wide tile only {ab_wide:.2f}
   ({p_wide:+.1f} %); both {ab_both:.2f} ({p_both:+.1f} %); the wide tile without the 16×16 level {ab_1024:.2f}. Cascade {abc_nowide:.2f} (no wide tile) → {abc_nofc:.2f} (no few-cout flavour) → {abc_def:.2f} MP/s.
 * HBM traffic of the family (`r06_hbm_traffic_and_mfma_util.json`, FETCH × 2 + WRITE, one lane): **{traffic_mb:.1f} MB per launch** against 194.8 MB algorithmic = **{t_ratio:.2f}×** ({t_strict:.2f}× strict; round 5: 311.2 MB,
