@@ -138,3 +138,32 @@ def test_unet_attention_blocks_use_the_mfma_kernel_and_match():
     ref2 = OracleUnet(cfg2, sd)(x2.cpu(), t[:1], [c[:1].cpu()])
     assert rel_rms(y2.cpu().numpy(), ref2.detach().numpy()) < 2e-2
     m.close(); m2.close()
+
+
+@pytest.mark.parametrize("B,H,D,Lq,Lk", [(1, 2, 64, 700, 1000), (1, 2, 40, 520, 4096), (1, 2, 32, 300, 513), (1, 2, 8, 130, 640),
+                                         (2, 8, 64, 4096, 1024), (2, 8, 40, 4096, 640)])   # the last two: 256 workgroups of 8 waves (the SD shapes' form)
+def test_pipelined_loop_is_bit_identical_to_the_unpipelined_one(B, H, D, Lq, Lk, tmp_path):
+    """Round 6: the software-pipelined tile loop (csrc/attn_mfma.hip, PIPE: >= 512 keys, head dims <= 64) issues the same MFMAs with the same operands in the same
+    order as the unpipelined loop -- plain (D % 16 == 0) and folded (D % 16 != 0) softmax forms, ragged last tile, odd and even tile counts.  The launcher reads its
+    A/B hook TD_ATTN_PIPE once per process, so each side runs in its own process; the outputs must be EQUAL, not close."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from terrain_diffusion_amd.attention import attention\n"
+        f"g = torch.Generator().manual_seed({D * 7 + Lk})\n"
+        f"q, k, v = (torch.randn({B}, {H}, L, {D}, generator=g) * s for L, s in (({Lq}, 1.3), ({Lk}, 0.9), ({Lk}, 2.0)))\n"
+        f"out = attention(q, k, v, scale={1.0 / math.sqrt(D)!r}).cpu()\n"
+        "assert torch.isfinite(out).all()\n"
+        "torch.save(out, sys.argv[1])\n")
+    outs = []
+    for pipe in ("0", "1"):
+        path = str(tmp_path / f"o{pipe}.pt")
+        env = dict(os.environ, TD_ATTN_PIPE=pipe)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(path))
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
